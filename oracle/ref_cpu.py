@@ -1,0 +1,320 @@
+"""ORACLE — test infrastructure only.  CPU fp32 restatement of the reference fusion path.
+
+This file is the *checker* for the MI355X HIP path.  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import it; the product
+package (``simple-multimodal_amd/``) never does, and fails loudly when its HIP library is absent.
+
+Every function restates, with explicit tensor arithmetic (no ``nn.MultiheadAttention``,
+no ``nn.LayerNorm``, no ``torch_geometric``), what one reference class computes.  Citations are
+relative to ``/root/reference``.  Parameters are passed as a flat ``dict`` keyed by the
+reference's own ``state_dict()`` names, so a reference checkpoint drives the oracle unchanged.
+
+Pinning status:
+  * everything except the GAT arithmetic is pinned by ``tools/capture_golden.py``, which imports
+    the reference's classes in the build container, loads identical weights and compares
+    outputs and gradients (<= 1e-5) before writing ``tests/golden/*.npz``;
+  * ``gat_dense`` (torch-geometric ``GATConv``, requirements.txt:34, unpinned ``>=2.3.0``, not
+    vendored, not installable offline) is **parity unpinned**: it restates PyG's published
+    GATConv algorithm on the constant 3-clique + self loops and is anchored only on the
+    reference's call sites (models/fusion_layers.py:223-232,253-289).
+
+Dropout: all functions take ``p_drop`` only to assert it is zero or the module is in eval —
+torch's CPU Philox stream cannot be reproduced on device, so parity runs use p = 0.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Tuple
+
+import torch
+
+Tensor = torch.Tensor
+Params = Dict[str, Tensor]
+
+
+# --------------------------------------------------------------------------------------
+# primitives
+# --------------------------------------------------------------------------------------
+def linear(x: Tensor, w: Tensor, b: Optional[Tensor] = None) -> Tensor:
+    """y = x W^T + b  (torch.nn.Linear semantics; weight is (out, in))."""
+    y = x.matmul(w.t())
+    return y if b is None else y + b
+
+
+def layer_norm(x: Tensor, g: Tensor, b: Tensor, eps: float = 1e-5) -> Tensor:
+    """nn.LayerNorm over the last dim, biased variance, eps inside the sqrt."""
+    mu = x.mean(dim=-1, keepdim=True)
+    xc = x - mu
+    var = (xc * xc).mean(dim=-1, keepdim=True)
+    return xc * torch.rsqrt(var + eps) * g + b
+
+
+def softmax_lastdim(s: Tensor) -> Tensor:
+    m = s.max(dim=-1, keepdim=True).values
+    e = torch.exp(s - m)
+    return e / e.sum(dim=-1, keepdim=True)
+
+
+def mha(P: Params, pre: str, query: Tensor, key_value: Tensor, num_heads: int
+        ) -> Tuple[Tensor, Tensor]:
+    """torch.nn.MultiheadAttention(batch_first=True, need_weights=True) forward.
+
+    Follows the explicit-scores path the reference always takes (it never passes
+    need_weights=False): packed in-projection, q scaled by 1/sqrt(dh) *before* QK^T, fp32
+    softmax over keys, P.V, out-projection; second result is the head-averaged weights.
+    Call sites: models/fusion_layers.py:161-163,204,432-434.
+    """
+    w_in, b_in = P[pre + "in_proj_weight"], P[pre + "in_proj_bias"]
+    w_out, b_out = P[pre + "out_proj.weight"], P[pre + "out_proj.bias"]
+    d = query.shape[-1]
+    dh = d // num_heads
+    q = linear(query, w_in[:d], b_in[:d])
+    k = linear(key_value, w_in[d:2 * d], b_in[d:2 * d])
+    v = linear(key_value, w_in[2 * d:], b_in[2 * d:])
+    B, Tq, _ = q.shape
+    Tk = k.shape[1]
+    q = q.reshape(B, Tq, num_heads, dh).permute(0, 2, 1, 3) * (1.0 / math.sqrt(dh))
+    k = k.reshape(B, Tk, num_heads, dh).permute(0, 2, 1, 3)
+    v = v.reshape(B, Tk, num_heads, dh).permute(0, 2, 1, 3)
+    probs = softmax_lastdim(q.matmul(k.transpose(-1, -2)))          # (B,H,Tq,Tk)
+    o = probs.matmul(v).permute(0, 2, 1, 3).reshape(B, Tq, d)
+    return linear(o, w_out, b_out), probs.mean(dim=1)
+
+
+# --------------------------------------------------------------------------------------
+# a1  CrossModalTransformer  (models/fusion_layers.py:182-211)
+# --------------------------------------------------------------------------------------
+def cross_modal_transformer(P: Params, pre: str, query: Tensor, key_value: Tensor,
+                            num_heads: int) -> Tensor:
+    a, _ = mha(P, pre + "attention.", query, key_value, num_heads)        # :204
+    x = layer_norm(query + a, P[pre + "norm1.weight"], P[pre + "norm1.bias"])   # :205
+    h = torch.relu(linear(x, P[pre + "ffn.0.weight"], P[pre + "ffn.0.bias"]))   # :196-197
+    f = linear(h, P[pre + "ffn.3.weight"], P[pre + "ffn.3.bias"])               # :199
+    return layer_norm(x + f, P[pre + "norm2.weight"], P[pre + "norm2.bias"])    # :209
+
+
+# --------------------------------------------------------------------------------------
+# a2  MultimodalTransformer  (models/fusion_layers.py:130-179)
+# --------------------------------------------------------------------------------------
+def multimodal_transformer(P: Params, pre: str, text: Tensor, audio: Tensor, video: Tensor,
+                           num_heads: int) -> Dict[str, Tensor]:
+    if text.dim() == 2:                                                   # :140-143
+        text, audio, video = text.unsqueeze(1), audio.unsqueeze(1), video.unsqueeze(1)
+    cm = lambda name, q, kv: cross_modal_transformer(P, pre + name + ".", q, kv, num_heads)
+    t_a, t_v = cm("text_to_audio", text, audio), cm("text_to_video", text, video)    # :146-147
+    a_t, a_v = cm("audio_to_text", audio, text), cm("audio_to_video", audio, video)  # :149-150
+    v_t, v_a = cm("video_to_text", video, text), cm("video_to_audio", video, audio)  # :152-153
+    et, ea, ev = text + t_a + t_v, audio + a_t + a_v, video + v_t + v_a              # :156-158
+    ta, _ = mha(P, pre + "text_self_attn.", et, et, num_heads)                       # :161
+    aa, _ = mha(P, pre + "audio_self_attn.", ea, ea, num_heads)
+    va, _ = mha(P, pre + "video_self_attn.", ev, ev, num_heads)
+    tp, ap, vp = ta.mean(dim=1), aa.mean(dim=1), va.mean(dim=1)                      # :166-168
+    fused = torch.relu(linear(torch.cat([tp, ap, vp], dim=-1),
+                              P[pre + "final_fusion.0.weight"], P[pre + "final_fusion.0.bias"]))
+    return {"fused_features": fused, "text_features": tp, "audio_features": ap,
+            "video_features": vp}
+
+
+# --------------------------------------------------------------------------------------
+# a4  EarlyFusion  (models/fusion_layers.py:30-43)
+# --------------------------------------------------------------------------------------
+def early_fusion(P: Params, pre: str, text: Tensor, audio: Tensor, video: Tensor) -> Tensor:
+    x = torch.cat([text, audio, video], dim=-1)
+    x = torch.relu(linear(x, P[pre + "fusion_layers.0.weight"], P[pre + "fusion_layers.0.bias"]))
+    return torch.relu(linear(x, P[pre + "fusion_layers.3.weight"], P[pre + "fusion_layers.3.bias"]))
+
+
+# --------------------------------------------------------------------------------------
+# a5  LateFusion  (models/fusion_layers.py:62-90)
+# --------------------------------------------------------------------------------------
+def late_fusion(P: Params, pre: str, text: Tensor, audio: Tensor, video: Tensor
+                ) -> Dict[str, Tensor]:
+    tl = linear(text, P[pre + "text_classifier.weight"], P[pre + "text_classifier.bias"])
+    al = linear(audio, P[pre + "audio_classifier.weight"], P[pre + "audio_classifier.bias"])
+    vl = linear(video, P[pre + "video_classifier.weight"], P[pre + "video_classifier.bias"])
+    w = softmax_lastdim(P[pre + "fusion_weights"])
+    return {"fused_logits": w[0] * tl + w[1] * al + w[2] * vl, "text_logits": tl,
+            "audio_logits": al, "video_logits": vl, "fusion_weights": w}
+
+
+# --------------------------------------------------------------------------------------
+# a6  GraphFusion  (models/fusion_layers.py:240-291) — GAT arithmetic PARITY UNPINNED
+# --------------------------------------------------------------------------------------
+def gat_dense(x: Tensor, w: Tensor, att_src: Tensor, att_dst: Tensor, bias: Tensor,
+              heads: int = 4, negative_slope: float = 0.2) -> Tensor:
+    """PyG ``GATConv(in, out, heads=4, concat=False)`` on a batch of fully connected 3-node
+    graphs with self loops (PyG's add_self_loops default), stated densely.
+
+    x: (B, 3, in);  w: (heads*out, in) shared source/target projection, no bias;
+    att_src/att_dst: (heads, out);  bias: (out,).
+    e[i, j] = leaky_relu(<h_j, att_src> + <h_i, att_dst>) is the score of edge j -> i;
+    alpha = softmax over the incoming j (PyG's softmax adds 1e-16 to the denominator);
+    out_i = mean_heads sum_j alpha[i, j] h_j + bias.
+    """
+    B, n, _ = x.shape
+    out = w.shape[0] // heads
+    h = linear(x, w).reshape(B, n, heads, out)                     # (B,3,H,C)
+    s_src = (h * att_src).sum(-1)                                  # (B,3,H)  indexed by j
+    s_dst = (h * att_dst).sum(-1)                                  # (B,3,H)  indexed by i
+    e = s_dst.unsqueeze(2) + s_src.unsqueeze(1)                    # (B,i,j,H)
+    e = torch.where(e >= 0, e, e * negative_slope)
+    m = e.max(dim=2, keepdim=True).values
+    ex = torch.exp(e - m)
+    alpha = ex / (ex.sum(dim=2, keepdim=True) + 1e-16)             # softmax over j
+    o = torch.einsum("bijh,bjhc->bihc", alpha, h)                  # (B,3,H,C)
+    return o.mean(dim=2) + bias
+
+
+def graph_fusion(P: Params, pre: str, text: Tensor, audio: Tensor, video: Tensor,
+                 num_layers: int) -> Tensor:
+    x = torch.stack([text, audio, video], dim=1) + P[pre + "node_type_embedding.weight"]  # :255-264
+    for l in range(num_layers):                                                           # :280-282
+        lp = f"{pre}gcn_layers.{l}."
+        x = torch.relu(gat_dense(x, P[lp + "lin.weight"], P[lp + "att_src"].reshape(4, -1),
+                                 P[lp + "att_dst"].reshape(4, -1), P[lp + "bias"]))
+    pooled = x.mean(dim=1)                                                                # :285-286
+    return linear(pooled, P[pre + "output_projection.weight"], P[pre + "output_projection.bias"])
+
+
+# --------------------------------------------------------------------------------------
+# a7  ContrastiveFusion  (models/fusion_layers.py:329-375)
+# --------------------------------------------------------------------------------------
+def l2_normalize(x: Tensor, eps: float = 1e-12) -> Tensor:
+    """F.normalize(x, dim=-1): x / max(||x||_2, eps)."""
+    return x / x.pow(2).sum(-1, keepdim=True).sqrt().clamp_min(eps)
+
+
+def cross_entropy_arange(sim: Tensor) -> Tensor:
+    """F.cross_entropy(sim, arange(B)) with mean reduction."""
+    m = sim.max(dim=-1, keepdim=True).values
+    lse = (sim - m).exp().sum(-1).log() + m.squeeze(-1)
+    return (lse - sim.diagonal()).mean()
+
+
+def info_nce(z1: Tensor, z2: Tensor, temperature: float) -> Tensor:
+    sim = z1.matmul(z2.t()) / temperature                                  # :366
+    return (cross_entropy_arange(sim) + cross_entropy_arange(sim.t())) / 2  # :372-375
+
+
+def contrastive_fusion(P: Params, pre: str, text: Tensor, audio: Tensor, video: Tensor,
+                       temperature: float, compute_contrastive_loss: bool = False
+                       ) -> Dict[str, Tensor]:
+    def proj(name, x):
+        h = torch.relu(linear(x, P[f"{pre}{name}.0.weight"], P[f"{pre}{name}.0.bias"]))
+        return l2_normalize(linear(h, P[f"{pre}{name}.2.weight"], P[f"{pre}{name}.2.bias"]))
+    tp, ap, vp = proj("text_projector", text), proj("audio_projector", audio), \
+        proj("video_projector", video)                                      # :338-340
+    losses = {}
+    if compute_contrastive_loss:                                            # :344-347
+        losses = {"text_audio": info_nce(tp, ap, temperature),
+                  "text_video": info_nce(tp, vp, temperature),
+                  "audio_video": info_nce(ap, vp, temperature)}
+    fused = torch.relu(linear(torch.cat([text, audio, video], dim=-1),
+                              P[pre + "fusion_layer.0.weight"], P[pre + "fusion_layer.0.bias"]))
+    return {"fused_features": fused, "text_proj": tp, "audio_proj": ap, "video_proj": vp,
+            "contrastive_losses": losses}
+
+
+# --------------------------------------------------------------------------------------
+# a8  AdaptiveFusion  (models/fusion_layers.py:414-452)
+# --------------------------------------------------------------------------------------
+def adaptive_fusion(P: Params, pre: str, text: Tensor, audio: Tensor, video: Tensor,
+                    num_heads: int) -> Dict[str, Tensor]:
+    tt = linear(text, P[pre + "text_transform.weight"], P[pre + "text_transform.bias"])
+    at = linear(audio, P[pre + "audio_transform.weight"], P[pre + "audio_transform.bias"])
+    vt = linear(video, P[pre + "video_transform.weight"], P[pre + "video_transform.bias"])
+    stacked = torch.stack([tt, at, vt], dim=1)                              # (B,3,d) :427-429
+    attended, weights = mha(P, pre + "attention.", stacked, stacked, num_heads)
+    cat = torch.cat([text, audio, video], dim=-1)
+    h = torch.relu(linear(cat, P[pre + "weight_predictor.0.weight"],
+                          P[pre + "weight_predictor.0.bias"]))
+    aw = softmax_lastdim(linear(h, P[pre + "weight_predictor.2.weight"],
+                                P[pre + "weight_predictor.2.bias"]))        # (B,3)
+    weighted = (attended * aw.unsqueeze(-1)).sum(dim=1)                     # :441-443
+    fused = torch.relu(linear(weighted, P[pre + "fusion_layer.0.weight"],
+                              P[pre + "fusion_layer.0.bias"]))
+    return {"fused_features": fused, "attention_weights": weights, "adaptive_weights": aw}
+
+
+# --------------------------------------------------------------------------------------
+# a9  HierarchicalFusion  (models/fusion_layers.py:478-520)
+# --------------------------------------------------------------------------------------
+def hierarchical_fusion(P: Params, pre: str, text: Tensor, audio: Tensor, video: Tensor, *,
+                        num_heads: int, graph_num_layers: int, temperature: float,
+                        compute_contrastive_loss: bool = False,
+                        mult_inputs: Optional[Tuple[Tensor, Tensor, Tensor]] = None
+                        ) -> Dict[str, Tensor]:
+    """``mult_inputs`` is the build-defined *hier-seq* composition:
+    when given, the MulT branch consumes those (B,T,d) sequences while the other four
+    branches consume the (B,d) tensors.  With ``mult_inputs=None`` this is the literal
+    reference semantics (*hier-ref*)."""
+    early = early_fusion(P, pre + "early_fusion.", text, audio, video)
+    mi = mult_inputs if mult_inputs is not None else (text, audio, video)
+    mult = multimodal_transformer(P, pre + "mult_fusion.", *mi, num_heads)
+    graph = graph_fusion(P, pre + "graph_fusion.", text, audio, video, graph_num_layers)
+    con = contrastive_fusion(P, pre + "contrastive_fusion.", text, audio, video, temperature,
+                             compute_contrastive_loss)
+    ada = adaptive_fusion(P, pre + "adaptive_fusion.", text, audio, video, num_heads)
+    allf = torch.cat([early, mult["fused_features"], graph, con["fused_features"],
+                      ada["fused_features"]], dim=-1)                       # :503-506
+    h = torch.relu(linear(allf, P[pre + "meta_fusion.0.weight"], P[pre + "meta_fusion.0.bias"]))
+    final = linear(h, P[pre + "meta_fusion.3.weight"], P[pre + "meta_fusion.3.bias"])
+    return {"fused_features": final, "early_features": early,
+            "mult_features": mult["fused_features"], "graph_features": graph,
+            "contrastive_features": con["fused_features"],
+            "adaptive_features": ada["fused_features"],
+            "contrastive_losses": con["contrastive_losses"],
+            "attention_weights": ada["attention_weights"],
+            "adaptive_weights": ada["adaptive_weights"]}
+
+
+# --------------------------------------------------------------------------------------
+# a10  encoder projection tails, AdapterLayer, ModalityDropout  (models/encoders.py)
+# --------------------------------------------------------------------------------------
+def adapter_layer(P: Params, pre: str, x: Tensor) -> Tensor:
+    """encoders.py:271-277 with dropout off."""
+    h = torch.relu(linear(x, P[pre + "down_project.weight"], P[pre + "down_project.bias"]))
+    return x + linear(h, P[pre + "up_project.weight"], P[pre + "up_project.bias"])
+
+
+def text_projection_tail(P: Params, pre: str, sequence_output: Tensor,
+                         attention_mask: Optional[Tensor], cls_pool: bool = True) -> Tensor:
+    """encoders.py:86-98: CLS token (model_type contains 'bert') or masked mean, then Linear."""
+    if cls_pool:
+        pooled = sequence_output[:, 0]
+    else:
+        m = attention_mask.unsqueeze(-1).to(sequence_output.dtype)
+        pooled = (sequence_output * m).sum(1) / m.sum(1).clamp_min(1e-9)
+    return linear(pooled, P[pre + "projection.weight"], P[pre + "projection.bias"])
+
+
+def seq_projection_tail(P: Params, pre: str, sequence_output: Tensor, attn_name: str,
+                        num_heads: int = 8) -> Tuple[Tensor, Tensor]:
+    """encoders.py:151-161 / :236-245: self-MHA over frames -> mean(T) -> Linear.
+    Returns (features, attended sequence)."""
+    att, _ = mha(P, pre + attn_name + ".", sequence_output, sequence_output, num_heads)
+    return linear(att.mean(dim=1), P[pre + "projection.weight"], P[pre + "projection.bias"]), att
+
+
+def modality_dropout_apply(text: Tensor, audio: Tensor, video: Tensor,
+                           keep_t: Tensor, keep_a: Tensor, keep_v: Tensor):
+    """encoders.py:316-319: multiply by (B,1) keep masks, **no** 1/(1-p) rescale.
+    Mask sampling (:303-314) is RNG and stays with the caller."""
+    return text * keep_t, audio * keep_a, video * keep_v
+
+
+# --------------------------------------------------------------------------------------
+# a11  model glue  (models/multimodal_model.py:147-164, 186-219)
+# --------------------------------------------------------------------------------------
+def emotion_classifier(P: Params, pre: str, x: Tensor) -> Tensor:
+    h = torch.relu(linear(x, P[pre + "classifier.0.weight"], P[pre + "classifier.0.bias"]))
+    return linear(h, P[pre + "classifier.3.weight"], P[pre + "classifier.3.bias"])
+
+
+def model_heads(P: Params, fused: Tensor) -> Dict[str, Tensor]:
+    logits = emotion_classifier(P, "classifier.", fused)
+    return {"emotion_logits": logits, "emotion_probs": softmax_lastdim(logits),
+            "valence": linear(fused, P["valence_regressor.weight"], P["valence_regressor.bias"]),
+            "arousal": linear(fused, P["arousal_regressor.weight"], P["arousal_regressor.bias"]),
+            "uncertainty": softmax_lastdim(
+                linear(fused, P["uncertainty_head.weight"], P["uncertainty_head.bias"]))}

@@ -1,0 +1,87 @@
+"""Shared test helpers: golden-fixture loading and oracle dispatch (test infrastructure)."""
+import json
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from mmfusion import synth
+from oracle import ref_cpu
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_fixture(name):
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False)
+    meta = json.loads(bytes(z["meta"]).decode())
+    fx = SimpleNamespace(meta=meta, out={}, gin=[], gsmall={})
+    for k in z.files:
+        if k.startswith("out/"):
+            fx.out[k[4:]] = torch.from_numpy(z[k])
+        elif k.startswith("gsmall/"):
+            fx.gsmall[k[7:]] = torch.from_numpy(z[k])
+    fx.gin = [torch.from_numpy(z[f"gin/{i}"]) for i in range(len(meta["Ts"]))]
+    return fx
+
+
+def fixture_params(meta):
+    return synth.make_params([(k, tuple(s)) for k, s in meta["shapes"]], seed=meta["weight_seed"])
+
+
+def fixture_inputs(meta):
+    return list(synth.make_features(meta["B"], meta["Ts"], meta["d"], seed=meta["input_seed"]))
+
+
+def cfg_from_meta(meta):
+    import config as cfgmod
+    cfg = cfgmod.ModelConfig()
+    for k, v in meta["cfg"].items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+def run_oracle(meta, P, inputs):
+    """Dispatch a fixture's class to oracle/ref_cpu.py."""
+    cfg = cfg_from_meta(meta)
+    H, c, kw = cfg.fusion_num_heads, meta["cls"], meta.get("kwargs", {})
+    if c == "EarlyFusion":
+        return ref_cpu.early_fusion(P, "", *inputs)
+    if c == "LateFusion":
+        return ref_cpu.late_fusion(P, "", *inputs)
+    if c == "CrossModalTransformer":
+        return ref_cpu.cross_modal_transformer(P, "", inputs[0], inputs[1], H)
+    if c == "MultimodalTransformer":
+        return ref_cpu.multimodal_transformer(P, "", *inputs, H)
+    if c == "ContrastiveFusion":
+        return ref_cpu.contrastive_fusion(P, "", *inputs, cfg.contrastive_temperature, **kw)
+    if c == "AdaptiveFusion":
+        return ref_cpu.adaptive_fusion(P, "", *inputs, H)
+    if c == "GraphFusion":
+        return ref_cpu.graph_fusion(P, "", *inputs, cfg.graph_num_layers)
+    if c == "HierarchicalFusion":
+        return ref_cpu.hierarchical_fusion(P, "", *inputs, num_heads=H,
+                                           graph_num_layers=cfg.graph_num_layers,
+                                           temperature=cfg.contrastive_temperature, **kw)
+    if c == "AdapterLayer":
+        return ref_cpu.adapter_layer(P, "", inputs[0])
+    raise KeyError(c)
+
+
+def oracle_fwd_bwd(meta, P=None, inputs=None):
+    """Run the oracle forward + probe-loss backward; returns (flat outputs, input grads, param grads)."""
+    P = P if P is not None else fixture_params(meta)
+    inputs = inputs if inputs is not None else fixture_inputs(meta)
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    xin = [t.clone().requires_grad_(True) for t in inputs]
+    out = run_oracle(meta, Pg, xin)
+    synth.probe_loss(out).backward()
+    flat = {k: v.detach() for k, v in synth.flatten_outputs(out).items()}
+    gp = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in Pg.items()}
+    return flat, [t.grad for t in xin], gp
+
+
+def rel_err(a, b):
+    """max |a-b| / max(|b|) — error relative to the tensor's scale."""
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
