@@ -1,0 +1,162 @@
+/* mmfusion.h — C ABI of libmmfusion.so: MI355X (gfx950) kernels for the cross-modal fusion path.
+ *
+ * The reference (nl1xx/simple-multimodal) is pure Python on stock torch.nn and has no FFI of its
+ * own, so this ABI is what the reference-side binding for the fusion path
+ * would call; each entry point names the reference arithmetic it replaces (paths relative to the
+ * reference root).  INTEGRATION.md shows the ctypes stub a maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is DEVICE memory owned by the caller
+ *     (activations, weights, outputs, saved statistics, workspaces); the library never
+ *     allocates, frees or synchronises;
+ *   - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*; NULL = the
+ *     default stream) and is safe to capture into a hipGraph: descriptor tables travel by value
+ *     in the kernel arguments;
+ *   - activations / weights are bf16 (bit pattern of the upper half of an IEEE f32), row-major,
+ *     leading dimensions in ELEMENTS; accumulation, softmax and LayerNorm statistics are f32;
+ *   - return value: MMF_OK or a negative MMF_E_* code; mmf_last_error() gives the thread-local
+ *     message.  No C++ exception crosses the boundary.
+ *   - alignment: all base pointers 16-byte aligned; leading dimensions and K multiples of 8
+ *     elements; N multiples of 4.  Violations return MMF_E_ALIGN / MMF_E_SHAPE, nothing is launched.
+ */
+#ifndef MMFUSION_H
+#define MMFUSION_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMF_ABI_VERSION 1
+
+enum {
+  MMF_OK = 0,
+  MMF_E_SHAPE = -1,
+  MMF_E_DTYPE = -2,
+  MMF_E_ALIGN = -3,
+  MMF_E_LAUNCH = -4,
+  MMF_E_UNSUPPORTED = -5
+};
+
+int mmf_version(void);
+const char* mmf_last_error(void);
+/* number of compute units of the current device (grid sizing on the host side) */
+int mmf_device_cu_count(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Grouped GEMM, bf16 in / f32 accumulate on the MFMA units (v_mfma_f32_16x16x32_bf16).
+ * Replaces every dense contraction of the path: nn.MultiheadAttention in/out projections
+ * (models/fusion_layers.py:188-191,204), the FFN (:195-200,208), and all fusion MLPs
+ * (:21-28,124-128,304-327,395-412,471-476), forward, dgrad and wgrad.
+ *
+ *   layout MMF_GEMM_NT:  C[m][n] = sum_k A[m][k]  * B[n][k]    (y = x W^T, forward)
+ *   layout MMF_GEMM_NN:  C[m][n] = sum_k A[m][k]  * B[k][n]    (dx = dy W, dgrad)
+ *   layout MMF_GEMM_TN:  C[m][n] = sum_k A[k][m]  * B[k][n]    (dW = dy^T x, wgrad)
+ *
+ * Epilogue, applied in this order on the f32 accumulator:
+ *   + bias[n] (MMF_EPI_BIAS) -> relu (MMF_EPI_RELU) -> * (aux[m][n] > 0) (MMF_EPI_MASK_AUX)
+ *   -> + aux[m][n] (MMF_EPI_ADD_AUX) -> + C_old[m][n] (MMF_EPI_ACCUM, f32 output only)
+ * aux is bf16 with leading dimension ldaux.  Output is bf16 or f32 (out_f32 != 0).
+ * One launch covers all problems (<= MMF_GEMM_MAX_PROBLEMS); problems must not alias outputs.
+ * ------------------------------------------------------------------------------------------ */
+#define MMF_GEMM_MAX_PROBLEMS 24
+enum { MMF_GEMM_NT = 0, MMF_GEMM_NN = 1, MMF_GEMM_TN = 2 };
+enum {
+  MMF_EPI_BIAS = 1,
+  MMF_EPI_RELU = 2,
+  MMF_EPI_MASK_AUX = 4,
+  MMF_EPI_ADD_AUX = 8,
+  MMF_EPI_ACCUM = 16
+};
+
+typedef struct mmf_gemm_problem {
+  const void* A;      /* bf16 */
+  const void* B;      /* bf16 */
+  void* C;            /* bf16 or f32 */
+  const float* bias;  /* f32 [N] or NULL */
+  const void* aux;    /* bf16 [M][ldaux] or NULL */
+  int32_t M, N, K;
+  int32_t lda, ldb, ldc, ldaux;
+} mmf_gemm_problem;
+
+int mmf_gemm_grouped(const mmf_gemm_problem* problems, int num_problems, int layout,
+                     int epilogue, int out_f32, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Grouped fused attention (flash-style: no (Tq,Tk) score matrix in HBM).
+ * Replaces q*scale, QK^T, softmax, P.V of F.multi_head_attention_forward as called at
+ * models/fusion_layers.py:161-163,204 (six cross blocks + three self blocks of MulT in ONE
+ * launch) and models/encoders.py:152-154,236-238.
+ * Row r = b*T + t of Q/K/V/O holds head h at columns [h*head_dim, (h+1)*head_dim).
+ * head_dim in {64, 96}.  LSE (f32, [B][H][Tq]) = log sum_k exp(scale * q.k) is saved for backward.
+ * Backward recomputes the probabilities; `delta` is a caller-provided f32 [B][H][Tq] workspace.
+ * ------------------------------------------------------------------------------------------ */
+#define MMF_ATTN_MAX_PROBLEMS 12
+typedef struct mmf_attn_problem {
+  const void* Q; const void* K; const void* V;   /* bf16 */
+  void* O;                                       /* bf16 */
+  float* LSE;                                    /* f32 [B*H*Tq] */
+  /* backward only (NULL in forward) */
+  const void* dO;                                /* bf16, same layout as O */
+  float* delta;                                  /* f32 [B*H*Tq] workspace */
+  void* dQ; void* dK; void* dV;                  /* bf16, same layouts/strides as Q, K, V */
+  int32_t B, H, Tq, Tk;
+  int32_t ldq, ldk, ldv, ldo;                    /* row strides (elements) of Q,K,V,O (and grads) */
+} mmf_attn_problem;
+
+int mmf_attn_fwd_grouped(const mmf_attn_problem* problems, int num_problems, int head_dim,
+                         float scale, void* stream);
+int mmf_attn_bwd_grouped(const mmf_attn_problem* problems, int num_problems, int head_dim,
+                         float scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * LayerNorm over the last dimension (eps inside the sqrt, biased variance, affine), one
+ * wavefront per row, f32 statistics by wave reduction.  Replaces nn.LayerNorm at
+ * models/fusion_layers.py:205,209 (the residual add is fused into the producing GEMM's epilogue).
+ * Forward saves mean and rstd (f32 [rows]).  Backward writes dx (bf16) and ADDS the
+ * per-column sums into dgamma/dbeta (f32 [d], caller zeroes or accumulates).
+ * ------------------------------------------------------------------------------------------ */
+#define MMF_LN_MAX_PROBLEMS 8
+typedef struct mmf_ln_problem {
+  const void* x;        /* bf16 [rows][d] */
+  void* y;              /* fwd: bf16 out.   bwd: unused */
+  const float* gamma;   /* f32 [d] */
+  const float* beta;    /* f32 [d] (fwd) */
+  float* mean;          /* f32 [rows]: written by fwd, read by bwd */
+  float* rstd;
+  const void* dy;       /* bwd: bf16 [rows][d] */
+  void* dx;             /* bwd: bf16 [rows][d] */
+  float* dgamma;        /* bwd: f32 [d], accumulated with atomics */
+  float* dbeta;
+  int32_t rows;
+} mmf_ln_problem;
+
+int mmf_layernorm_fwd_grouped(const mmf_ln_problem* problems, int num_problems, int d, float eps,
+                              void* stream);
+int mmf_layernorm_bwd_grouped(const mmf_ln_problem* problems, int num_problems, int d,
+                              void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Streaming helpers (HBM-bound, 16-byte vector accesses)
+ * ------------------------------------------------------------------------------------------ */
+/* dst_bf16[i] = bf16(src_f32[i]); n multiple of 8 not required */
+int mmf_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
+int mmf_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream);
+/* y = a + b + c (bf16); models/fusion_layers.py:156-158.  c may be NULL (y = a + b). */
+int mmf_add3_bf16(const void* a, const void* b, const void* c, void* y, int64_t n, void* stream);
+/* y[b][j] = mean_t x[b][t][j]  (models/fusion_layers.py:166-168); x bf16 [B][T][d], y bf16 with
+ * row stride ldy (lets the three pooled modalities land side by side = torch.cat, :171). */
+int mmf_meanpool_fwd(const void* x, void* y, int B, int T, int d, int ldy, void* stream);
+/* dx[b][t][j] = dy[b][j] / T ; dy bf16 with row stride lddy */
+int mmf_meanpool_bwd(const void* dy, void* dx, int B, int T, int d, int lddy, void* stream);
+/* out[n] (+)= sum_m x[m][n]; x bf16 [M][ldx]; out f32, atomically accumulated (bias gradients) */
+int mmf_colsum_bf16(const void* x, float* out, int M, int N, int ldx, void* stream);
+/* relu backward on bf16: dx = dy * (y > 0) */
+int mmf_relu_bwd_bf16(const void* dy, const void* y, void* dx, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMFUSION_H */

@@ -1,0 +1,555 @@
+// Grouped fused attention for the fusion path (q*scale, QK^T, softmax, P.V of
+// F.multi_head_attention_forward as called at models/fusion_layers.py:161-163,204): forward with
+// log-sum-exp, and a recompute backward (dQ kernel + dK/dV kernel, no atomics, deterministic).
+//
+// All nine attentions of a MulT pass (6 cross + 3 self, unequal Tq/Tk) go out as ONE launch.
+// MFMA: v_mfma_f32_32x32x16_bf16.  The products are oriented so that every probability tile stays
+// in registers between its two uses (guide section 3, "An accumulator tile as the next MFMA's
+// operand"):
+//   forward / dQ  : S^T[key][q] = K.Q^T  -> the query is the LANE: row max / row sum / LSE / delta
+//                   are per-lane scalars (one cross-half shuffle), P^T feeds O^T = V^T.P^T and
+//                   dS^T feeds dQ^T = K^T.dS^T straight from the accumulator registers;
+//   dK/dV         : S[q][key] = Q.K^T    -> the key is the lane; each wave keeps dK^T, dV^T of its
+//                   32 keys in accumulators while the workgroup sweeps the query tiles.
+// K/V (forward, dQ) and Q/dO (dK/dV) tiles are staged HBM -> registers -> LDS, double-buffered,
+// one barrier per tile; rows are padded by 16 B ([.][DH+8]) so the ds_read_b128 row reads are
+// conflict-free, the transposed operands come from the same image via ds_read_b64_tr_b16.
+// Softmax runs in the exp2 domain in f32; masked (>= Tk) keys get -1e30.
+#include "mmf_internal.h"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+constexpr float NEG_BIG = -1.0e30f;
+
+struct AttnArgs {
+  int nprob;
+  float scale;
+  int blk_start[MMF_ATTN_MAX_PROBLEMS + 1];
+  mmf_attn_problem p[MMF_ATTN_MAX_PROBLEMS];
+};
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// ---- LDS tile helpers: image [rows][DH + 8] bf16 ------------------------------------------------
+// Stage a [ROWS][DH] tile of a (T, ld) matrix whose (b, h) origin is `base`; rows >= T read as zero.
+template <int DH, int ROWS>
+struct TileStage {
+  static constexpr int CPR = DH / 8;                      // 16-B chunks per row
+  static constexpr int PER_THREAD = ROWS * CPR / NT;
+  static_assert(ROWS * CPR % NT == 0, "tile must split evenly over the workgroup");
+  u32x4_t r[PER_THREAD];
+  __device__ __forceinline__ void load(const unsigned short* __restrict__ base, int ld, int row0, int T, int tid) {
+#pragma unroll
+    for (int i = 0; i < PER_THREAD; ++i) {
+      const int c = tid + NT * i;
+      const int row = c / CPR, ch = c % CPR;
+      u32x4_t v = {0u, 0u, 0u, 0u};
+      if (row0 + row < T) v = *reinterpret_cast<const u32x4_t*>(base + (size_t)(row0 + row) * ld + ch * 8);
+      r[i] = v;
+    }
+  }
+  __device__ __forceinline__ void store(char* tile, int tid) const {
+#pragma unroll
+    for (int i = 0; i < PER_THREAD; ++i) {
+      const int c = tid + NT * i;
+      const int row = c / CPR, ch = c % CPR;
+      *reinterpret_cast<u32x4_t*>(tile + row * ((DH + 8) * 2) + ch * 16) = r[i];
+    }
+  }
+};
+
+// Row fragment (MFMA 32x32x16 A or B operand whose 32-index is the tile ROW): lane l gets
+// tile[row0 + (l & 31)][16 ks + 8 (l >> 5) + 0..7].
+template <int DH>
+__device__ __forceinline__ bf16x8_t row_frag(const char* tile, int row0, int ks, int lane) {
+  return *reinterpret_cast<const bf16x8_t*>(tile + (row0 + (lane & 31)) * ((DH + 8) * 2) +
+                                            (2 * ks + (lane >> 5)) * 16);
+}
+
+// Transposed fragment (A operand X^T[i = column][k = row]) for the 16 tile rows [r0, r0+16) and the
+// 32 columns [c0, c0+32): element j of lane (i = l & 31, h = l >> 5) is
+// tile[r0 + 8 (j >> 2) + 4 h + (j & 3)][c0 + i] — the k order in which an accumulator tile presents
+// its rows when it is used as the other operand.
+template <int DH>
+__device__ __forceinline__ bf16x8_t tr_frag(const char* tile, int r0, int c0, int lane) {
+  constexpr int SB = (DH + 8) * 2;
+  const int h = lane >> 5, g = (lane >> 4) & 1, q = (lane >> 2) & 3, p = lane & 3;
+  const char* a = tile + (r0 + 4 * h + q) * SB + (c0 + 16 * g + 4 * p) * 2;
+  const s16x4_t lo = lds_read_tr16(a);
+  const s16x4_t hi = lds_read_tr16(a + 8 * SB);
+  const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+
+// registers 8s..8s+7 of a 32x32 accumulator as a bf16 operand fragment
+__device__ __forceinline__ bf16x8_t acc_frag(const f32x16_t& x, int s) {
+  const u32x4_t w = {pack_bf16x2(x[8 * s + 0], x[8 * s + 1]), pack_bf16x2(x[8 * s + 2], x[8 * s + 3]),
+                     pack_bf16x2(x[8 * s + 4], x[8 * s + 5]), pack_bf16x2(x[8 * s + 6], x[8 * s + 7])};
+  return __builtin_bit_cast(bf16x8_t, w);
+}
+
+// Lane-resident row fragments of 32 rows taken directly from HBM (Q in forward/dQ, K/V in dK/dV):
+// lane l holds row (row0 + (l & 31)), columns 16 ks + 8 (l >> 5) + 0..7; rows >= T are zero.
+template <int DH>
+__device__ __forceinline__ void load_row_frags(bf16x8_t (&f)[DH / 16], const unsigned short* __restrict__ base,
+                                               int ld, int row0, int T, int lane) {
+  const int row = row0 + (lane & 31);
+#pragma unroll
+  for (int ks = 0; ks < DH / 16; ++ks) {
+    u32x4_t v = {0u, 0u, 0u, 0u};
+    if (row < T) v = *reinterpret_cast<const u32x4_t*>(base + (size_t)row * ld + 16 * ks + 8 * (lane >> 5));
+    f[ks] = __builtin_bit_cast(bf16x8_t, v);
+  }
+}
+
+// store a [d][q or key] accumulator set as rows of a (T, ld) bf16 matrix: lane owns row (row0 + (l&31)),
+// register 4g+i of tile dt is column 32 dt + 8 g + 4 (l>>5) + i.
+template <int DH>
+__device__ __forceinline__ void store_rows(const f32x16_t (&o)[DH / 32], float mul, unsigned short* __restrict__ base,
+                                           int ld, int row0, int T, int lane) {
+  const int row = row0 + (lane & 31);
+  if (row >= T) return;
+  unsigned short* p = base + (size_t)row * ld + 4 * (lane >> 5);
+#pragma unroll
+  for (int dt = 0; dt < DH / 32; ++dt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const u32x2_t w = {pack_bf16x2(o[dt][4 * g + 0] * mul, o[dt][4 * g + 1] * mul),
+                         pack_bf16x2(o[dt][4 * g + 2] * mul, o[dt][4 * g + 3] * mul)};
+      *reinterpret_cast<u32x2_t*>(p + 32 * dt + 8 * g) = w;
+    }
+}
+
+__device__ __forceinline__ int find_problem(const AttnArgs& a, int bid) {
+  int pi = 0;
+  while (pi + 1 < a.nprob && bid >= a.blk_start[pi + 1]) ++pi;
+  return pi;
+}
+
+// ================================================================================================
+// forward: workgroup = 128 query rows of one (b, h); wave = 32 query rows; KV tiles of 64 keys
+// ================================================================================================
+template <int DH>
+__global__ __launch_bounds__(NT)
+void attn_fwd_kernel(const AttnArgs a) {
+  constexpr int KS = DH / 16, DT = DH / 32;
+  constexpr int TILE_B = 64 * (DH + 8) * 2;
+  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_B];      // [buf][K | V]
+
+  const int pi = find_problem(a, blockIdx.x);
+  const mmf_attn_problem& P = a.p[pi];
+  const int Tq = P.Tq, Tk = P.Tk, H = P.H;
+  const int nqt = (Tq + 127) / 128;
+  const int idx = blockIdx.x - a.blk_start[pi];
+  const int bh = idx / nqt, qt = idx % nqt;
+  const int b = bh / H, h = bh % H;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+  const int q0 = qt * 128 + wave * 32;
+
+  const unsigned short* Qg = static_cast<const unsigned short*>(P.Q) + (size_t)b * Tq * P.ldq + h * DH;
+  const unsigned short* Kg = static_cast<const unsigned short*>(P.K) + (size_t)b * Tk * P.ldk + h * DH;
+  const unsigned short* Vg = static_cast<const unsigned short*>(P.V) + (size_t)b * Tk * P.ldv + h * DH;
+
+  bf16x8_t qf[KS];
+  load_row_frags<DH>(qf, Qg, P.ldq, q0, Tq, lane);
+
+  f32x16_t o[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+  float m = NEG_BIG, l = 0.f;
+  const float c = a.scale * LOG2E;
+
+  TileStage<DH, 64> sk, sv;
+  const int ntiles = (Tk + 63) / 64;
+  sk.load(Kg, P.ldk, 0, Tk, tid);
+  sv.load(Vg, P.ldv, 0, Tk, tid);
+  sk.store(smem, tid);
+  sv.store(smem + TILE_B, tid);
+  __syncthreads();
+
+  int cur = 0;
+  for (int j = 0; j < ntiles; ++j) {
+    const bool more = j + 1 < ntiles;
+    if (more) {
+      sk.load(Kg, P.ldk, (j + 1) * 64, Tk, tid);
+      sv.load(Vg, P.ldv, (j + 1) * 64, Tk, tid);
+    }
+    const char* sK = smem + cur * 2 * TILE_B;
+    const char* sV = sK + TILE_B;
+    const int kb = j * 64;
+
+    f32x16_t s[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<DH>(sK, 32 * kt, ks, lane), qf[ks], s[kt], 0, 0, 0);
+    }
+    // scale into the exp2 domain, mask the ragged tail, running max
+    const bool ragged = kb + 64 > Tk;
+    float mx = NEG_BIG;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = s[kt][r] * c;
+        if (ragged) {
+          const int key = kb + 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * half;
+          v = key < Tk ? v : NEG_BIG;
+        }
+        s[kt][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mnew = fmaxf(m, mx);
+    const float alpha = fast_exp2(m - mnew);
+    m = mnew;
+    float rs = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = fast_exp2(s[kt][r] - mnew);
+        s[kt][r] = p;
+        rs += p;
+      }
+    l = l * alpha + rs;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+    // O^T += V^T . P^T
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss) {
+        const bf16x8_t pf = acc_frag(s[kt], ss);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<DH>(sV, 32 * kt + 16 * ss, 32 * dt, lane), pf, o[dt], 0, 0, 0);
+      }
+    if (more) {
+      char* d = smem + (cur ^ 1) * 2 * TILE_B;
+      sk.store(d, tid);
+      sv.store(d + TILE_B, tid);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  l += __shfl_xor(l, 32, 64);
+  const float inv = 1.f / l;
+  unsigned short* Og = static_cast<unsigned short*>(P.O) + (size_t)b * Tq * P.ldo + h * DH;
+  store_rows<DH>(o, inv, Og, P.ldo, q0, Tq, lane);
+  const int qrow = q0 + (lane & 31);
+  if (half == 0 && qrow < Tq) P.LSE[(size_t)bh * Tq + qrow] = m * LN2 + __logf(l);
+}
+
+// ================================================================================================
+// backward, dQ (+ delta): same sweep as the forward; per KV tile
+//   S^T = K.Q^T, P^T = exp(S^T*scale - LSE), dP^T = V.dO^T, dS^T = P^T (dP^T - delta), dQ^T += K^T.dS^T
+// ================================================================================================
+template <int DH>
+__global__ __launch_bounds__(NT)
+void attn_bwd_dq_kernel(const AttnArgs a) {
+  constexpr int KS = DH / 16, DT = DH / 32;
+  constexpr int TILE_B = 64 * (DH + 8) * 2;
+  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_B];
+
+  const int pi = find_problem(a, blockIdx.x);
+  const mmf_attn_problem& P = a.p[pi];
+  const int Tq = P.Tq, Tk = P.Tk, H = P.H;
+  const int nqt = (Tq + 127) / 128;
+  const int idx = blockIdx.x - a.blk_start[pi];
+  const int bh = idx / nqt, qt = idx % nqt;
+  const int b = bh / H, h = bh % H;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+  const int q0 = qt * 128 + wave * 32;
+  const int qrow = q0 + (lane & 31);
+
+  const size_t qoff = (size_t)b * Tq * P.ldq + h * DH, ooff = (size_t)b * Tq * P.ldo + h * DH;
+  const unsigned short* Qg = static_cast<const unsigned short*>(P.Q) + qoff;
+  const unsigned short* Og = static_cast<const unsigned short*>(P.O) + ooff;
+  const unsigned short* dOg = static_cast<const unsigned short*>(P.dO) + ooff;
+  const unsigned short* Kg = static_cast<const unsigned short*>(P.K) + (size_t)b * Tk * P.ldk + h * DH;
+  const unsigned short* Vg = static_cast<const unsigned short*>(P.V) + (size_t)b * Tk * P.ldv + h * DH;
+
+  bf16x8_t qf[KS], dof[KS];
+  load_row_frags<DH>(qf, Qg, P.ldq, q0, Tq, lane);
+  load_row_frags<DH>(dof, dOg, P.ldo, q0, Tq, lane);
+  // delta[q] = sum_d dO[q][d] * O[q][d]  (each half-lane pair covers the row once)
+  float delta = 0.f;
+  {
+    bf16x8_t of[KS];
+    load_row_frags<DH>(of, Og, P.ldo, q0, Tq, lane);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const u32x4_t x = __builtin_bit_cast(u32x4_t, of[ks]), y = __builtin_bit_cast(u32x4_t, dof[ks]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) delta += bf16lo(x[e]) * bf16lo(y[e]) + bf16hi(x[e]) * bf16hi(y[e]);
+    }
+    delta += __shfl_xor(delta, 32, 64);
+    if (half == 0 && qrow < Tq) P.delta[(size_t)bh * Tq + qrow] = delta;
+  }
+  const float c = a.scale * LOG2E;
+  const float lse2 = (qrow < Tq ? P.LSE[(size_t)bh * Tq + qrow] : 0.f) * LOG2E;
+
+  f32x16_t dq[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
+
+  TileStage<DH, 64> sk, sv;
+  const int ntiles = (Tk + 63) / 64;
+  sk.load(Kg, P.ldk, 0, Tk, tid);
+  sv.load(Vg, P.ldv, 0, Tk, tid);
+  sk.store(smem, tid);
+  sv.store(smem + TILE_B, tid);
+  __syncthreads();
+
+  int cur = 0;
+  for (int j = 0; j < ntiles; ++j) {
+    const bool more = j + 1 < ntiles;
+    if (more) {
+      sk.load(Kg, P.ldk, (j + 1) * 64, Tk, tid);
+      sv.load(Vg, P.ldv, (j + 1) * 64, Tk, tid);
+    }
+    const char* sK = smem + cur * 2 * TILE_B;
+    const char* sV = sK + TILE_B;
+    const int kb = j * 64;
+    const bool ragged = kb + 64 > Tk;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      f32x16_t s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<DH>(sK, 32 * kt, ks, lane), qf[ks], s, 0, 0, 0);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<DH>(sV, 32 * kt, ks, lane), dof[ks], dp, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float p = fast_exp2(s[r] * c - lse2);
+        if (ragged) {
+          const int key = kb + 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * half;
+          p = key < Tk ? p : 0.f;
+        }
+        s[r] = p * (dp[r] - delta);                       // dS^T (scale applied at the store)
+      }
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss) {
+        const bf16x8_t dsf = acc_frag(s, ss);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+          dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<DH>(sK, 32 * kt + 16 * ss, 32 * dt, lane), dsf, dq[dt], 0, 0, 0);
+      }
+    }
+    if (more) {
+      char* d = smem + (cur ^ 1) * 2 * TILE_B;
+      sk.store(d, tid);
+      sv.store(d + TILE_B, tid);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  unsigned short* dQg = static_cast<unsigned short*>(P.dQ) + qoff;
+  store_rows<DH>(dq, a.scale, dQg, P.ldq, q0, Tq, lane);
+}
+
+// ================================================================================================
+// backward, dK and dV: workgroup = 128 keys of one (b, h); wave = 32 keys kept in registers with
+// their dK^T / dV^T accumulators; sweep over query tiles of 64 rows (Q and dO staged in LDS).
+//   S = Q.K^T, P = exp(S*scale - LSE[q]), dV^T += dO^T.P, dP = dO.V^T, dS = P (dP - delta[q]),
+//   dK^T += Q^T.dS
+// ================================================================================================
+template <int DH>
+__global__ __launch_bounds__(NT)
+void attn_bwd_dkv_kernel(const AttnArgs a) {
+  constexpr int KS = DH / 16, DT = DH / 32;
+  constexpr int TILE_B = 64 * (DH + 8) * 2;
+  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_B + 2 * 2 * 64 * 4];   // [buf][Q | dO], [buf][lse2 | delta]
+  float* sstat = reinterpret_cast<float*>(smem + 4 * TILE_B);
+
+  const int pi = find_problem(a, blockIdx.x);
+  const mmf_attn_problem& P = a.p[pi];
+  const int Tq = P.Tq, Tk = P.Tk, H = P.H;
+  const int nkt = (Tk + 127) / 128;
+  const int idx = blockIdx.x - a.blk_start[pi];
+  const int bh = idx / nkt, ktile = idx % nkt;
+  const int b = bh / H, h = bh % H;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+  const int k0 = ktile * 128 + wave * 32;
+  const bool wave_active = k0 < Tk;                                   // wave-uniform
+
+  const size_t ooff = (size_t)b * Tq * P.ldo + h * DH;
+  const unsigned short* Qg = static_cast<const unsigned short*>(P.Q) + (size_t)b * Tq * P.ldq + h * DH;
+  const unsigned short* dOg = static_cast<const unsigned short*>(P.dO) + ooff;
+  const size_t koff = (size_t)b * Tk * P.ldk + h * DH, voff = (size_t)b * Tk * P.ldv + h * DH;
+  const unsigned short* Kg = static_cast<const unsigned short*>(P.K) + koff;
+  const unsigned short* Vg = static_cast<const unsigned short*>(P.V) + voff;
+  const float* LSEg = P.LSE + (size_t)bh * Tq;
+  const float* DELg = P.delta + (size_t)bh * Tq;
+
+  bf16x8_t kf[KS], vf[KS];
+  load_row_frags<DH>(kf, Kg, P.ldk, k0, Tk, lane);
+  load_row_frags<DH>(vf, Vg, P.ldv, k0, Tk, lane);
+
+  f32x16_t dk[DT], dv[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
+  const float c = a.scale * LOG2E;
+
+  TileStage<DH, 64> sq, sdo;
+  float stat = 0.f;                                                   // threads 0..63: lse2, 64..127: delta
+  auto load_stat = [&](int qb) {
+    if (tid < 128) {
+      const int q = qb + (tid & 63);
+      if (tid < 64) stat = q < Tq ? LSEg[q] * LOG2E : 1.0e30f;        // rows >= Tq: P = exp2(-inf) = 0
+      else          stat = q < Tq ? DELg[q] : 0.f;
+    }
+  };
+  const int ntiles = (Tq + 63) / 64;
+  sq.load(Qg, P.ldq, 0, Tq, tid);
+  sdo.load(dOg, P.ldo, 0, Tq, tid);
+  load_stat(0);
+  sq.store(smem, tid);
+  sdo.store(smem + TILE_B, tid);
+  if (tid < 128) sstat[tid] = stat;
+  __syncthreads();
+
+  int cur = 0;
+  for (int j = 0; j < ntiles; ++j) {
+    const bool more = j + 1 < ntiles;
+    if (more) {
+      sq.load(Qg, P.ldq, (j + 1) * 64, Tq, tid);
+      sdo.load(dOg, P.ldo, (j + 1) * 64, Tq, tid);
+      load_stat((j + 1) * 64);
+    }
+    const char* sQ = smem + cur * 2 * TILE_B;
+    const char* sdO = sQ + TILE_B;
+    const float* sl = sstat + cur * 128;
+    if (wave_active) {
+#pragma unroll
+      for (int qs = 0; qs < 2; ++qs) {
+        f32x16_t s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<DH>(sQ, 32 * qs, ks, lane), kf[ks], s, 0, 0, 0);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<DH>(sdO, 32 * qs, ks, lane), vf[ks], dp, 0, 0, 0);
+        f32x16_t ds;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4_t l4 = *reinterpret_cast<const f32x4_t*>(sl + 32 * qs + 8 * g + 4 * half);
+          const f32x4_t d4 = *reinterpret_cast<const f32x4_t*>(sl + 64 + 32 * qs + 8 * g + 4 * half);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float p = fast_exp2(s[4 * g + i] * c - l4[i]);
+            s[4 * g + i] = p;
+            ds[4 * g + i] = p * (dp[4 * g + i] - d4[i]);
+          }
+        }
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss) {
+          const bf16x8_t pf = acc_frag(s, ss), dsf = acc_frag(ds, ss);
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) {
+            dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<DH>(sdO, 32 * qs + 16 * ss, 32 * dt, lane), pf, dv[dt], 0, 0, 0);
+            dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<DH>(sQ, 32 * qs + 16 * ss, 32 * dt, lane), dsf, dk[dt], 0, 0, 0);
+          }
+        }
+      }
+    }
+    if (more) {
+      char* d = smem + (cur ^ 1) * 2 * TILE_B;
+      sq.store(d, tid);
+      sdo.store(d + TILE_B, tid);
+      if (tid < 128) sstat[(cur ^ 1) * 128 + tid] = stat;
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  if (wave_active) {
+    store_rows<DH>(dk, a.scale, static_cast<unsigned short*>(P.dK) + koff, P.ldk, k0, Tk, lane);
+    store_rows<DH>(dv, 1.f, static_cast<unsigned short*>(P.dV) + voff, P.ldv, k0, Tk, lane);
+  }
+}
+
+int validate(const char* who, const mmf_attn_problem* p, int n, int head_dim, bool bwd) {
+  if (!p || n <= 0 || n > MMF_ATTN_MAX_PROBLEMS) MMF_FAIL(MMF_E_SHAPE, "%s: num_problems=%d out of range", who, n);
+  if (head_dim != 64 && head_dim != 96) MMF_FAIL(MMF_E_UNSUPPORTED, "%s: head_dim=%d (supported: 64, 96)", who, head_dim);
+  for (int i = 0; i < n; ++i) {
+    const mmf_attn_problem& q = p[i];
+    if (q.B <= 0 || q.H <= 0 || q.Tq <= 0 || q.Tk <= 0) MMF_FAIL(MMF_E_SHAPE, "%s[%d]: B=%d H=%d Tq=%d Tk=%d", who, i, q.B, q.H, q.Tq, q.Tk);
+    const int w = q.H * head_dim;
+    if (q.ldq < w || q.ldk < w || q.ldv < w || q.ldo < w || (q.ldq & 7) || (q.ldk & 7) || (q.ldv & 7) || (q.ldo & 7))
+      MMF_FAIL(MMF_E_ALIGN, "%s[%d]: row strides must be >= H*head_dim and multiples of 8", who, i);
+    if (!q.Q || !q.K || !q.V || !q.O || !q.LSE) MMF_FAIL(MMF_E_SHAPE, "%s[%d]: null operand", who, i);
+    if (!mmf_aligned16(q.Q) || !mmf_aligned16(q.K) || !mmf_aligned16(q.V) || !mmf_aligned16(q.O))
+      MMF_FAIL(MMF_E_ALIGN, "%s[%d]: Q/K/V/O must be 16-byte aligned", who, i);
+    if (bwd) {
+      if (!q.dO || !q.delta || !q.dQ || !q.dK || !q.dV) MMF_FAIL(MMF_E_SHAPE, "%s[%d]: null gradient operand", who, i);
+      if (!mmf_aligned16(q.dO) || !mmf_aligned16(q.dQ) || !mmf_aligned16(q.dK) || !mmf_aligned16(q.dV))
+        MMF_FAIL(MMF_E_ALIGN, "%s[%d]: gradient pointers must be 16-byte aligned", who, i);
+    }
+  }
+  return MMF_OK;
+}
+
+int fill_args(AttnArgs& a, const mmf_attn_problem* p, int n, float scale, bool by_keys) {
+  a.nprob = n; a.scale = scale;
+  int total = 0;
+  for (int i = 0; i < n; ++i) {
+    a.blk_start[i] = total;
+    const int T = by_keys ? p[i].Tk : p[i].Tq;
+    total += p[i].B * p[i].H * ((T + 127) / 128);
+    a.p[i] = p[i];
+  }
+  a.blk_start[n] = total;
+  return total;
+}
+
+}  // namespace
+
+extern "C" int mmf_attn_fwd_grouped(const mmf_attn_problem* problems, int num_problems, int head_dim,
+                                    float scale, void* stream) {
+  if (int rc = validate("mmf_attn_fwd_grouped", problems, num_problems, head_dim, false)) return rc;
+  AttnArgs a;
+  const int total = fill_args(a, problems, num_problems, scale, false);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (head_dim == 96) hipLaunchKernelGGL(attn_fwd_kernel<96>, dim3(total), dim3(NT), 0, s, a);
+  else                hipLaunchKernelGGL(attn_fwd_kernel<64>, dim3(total), dim3(NT), 0, s, a);
+  MMF_CHECK_LAUNCH("mmf_attn_fwd_grouped");
+  return MMF_OK;
+}
+
+extern "C" int mmf_attn_bwd_grouped(const mmf_attn_problem* problems, int num_problems, int head_dim,
+                                    float scale, void* stream) {
+  if (int rc = validate("mmf_attn_bwd_grouped", problems, num_problems, head_dim, true)) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  AttnArgs a;
+  int total = fill_args(a, problems, num_problems, scale, false);          // dQ (+ delta) first
+  if (head_dim == 96) hipLaunchKernelGGL(attn_bwd_dq_kernel<96>, dim3(total), dim3(NT), 0, s, a);
+  else                hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, dim3(total), dim3(NT), 0, s, a);
+  MMF_CHECK_LAUNCH("mmf_attn_bwd_grouped(dq)");
+  total = fill_args(a, problems, num_problems, scale, true);               // then dK/dV (reads delta)
+  if (head_dim == 96) hipLaunchKernelGGL(attn_bwd_dkv_kernel<96>, dim3(total), dim3(NT), 0, s, a);
+  else                hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, dim3(total), dim3(NT), 0, s, a);
+  MMF_CHECK_LAUNCH("mmf_attn_bwd_grouped(dkv)");
+  return MMF_OK;
+}

@@ -1,0 +1,245 @@
+// HBM-bound streaming helpers of the fusion path: casts, 3-way residual sum
+// (models/fusion_layers.py:156-158), mean over T (:166-168) and its backward, column sums (bias
+// gradients), relu backward.  All use 16-byte accesses per lane and grid-stride loops capped at
+// 2048 workgroups (guide: Guideline 11/13).
+#include "mmf_internal.h"
+
+namespace {
+
+constexpr int EW_THREADS = 256;
+inline int ew_grid(int64_t nvec) {
+  int64_t g = (nvec + EW_THREADS - 1) / EW_THREADS;
+  if (g > 2048) g = 2048;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+__global__ __launch_bounds__(EW_THREADS)
+void cast_f32_bf16_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, int64_t n) {
+  const int64_t nvec = n >> 3;
+  const int64_t stride = (int64_t)gridDim.x * EW_THREADS;
+  for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < nvec; i += stride) {
+    const f32x4_t a = *reinterpret_cast<const f32x4_t*>(src + i * 8);
+    const f32x4_t b = *reinterpret_cast<const f32x4_t*>(src + i * 8 + 4);
+    u32x4_t o = {pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(b[0], b[1]),
+                 pack_bf16x2(b[2], b[3])};
+    *reinterpret_cast<u32x4_t*>(dst + i * 8) = o;
+  }
+  if (blockIdx.x == 0) {                              // tail (n % 8 elements)
+    const int64_t t = (nvec << 3) + threadIdx.x;
+    if (t < n) dst[t] = f32_to_bf16_bits(src[t]);
+  }
+}
+
+__global__ __launch_bounds__(EW_THREADS)
+void cast_bf16_f32_kernel(const unsigned short* __restrict__ src, float* __restrict__ dst, int64_t n) {
+  const int64_t nvec = n >> 3;
+  const int64_t stride = (int64_t)gridDim.x * EW_THREADS;
+  for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < nvec; i += stride) {
+    const u32x4_t w = *reinterpret_cast<const u32x4_t*>(src + i * 8);
+    *reinterpret_cast<f32x4_t*>(dst + i * 8) = f32x4_t{bf16lo(w[0]), bf16hi(w[0]), bf16lo(w[1]), bf16hi(w[1])};
+    *reinterpret_cast<f32x4_t*>(dst + i * 8 + 4) = f32x4_t{bf16lo(w[2]), bf16hi(w[2]), bf16lo(w[3]), bf16hi(w[3])};
+  }
+  if (blockIdx.x == 0) {
+    const int64_t t = (nvec << 3) + threadIdx.x;
+    if (t < n) dst[t] = bf16_bits_to_f32(src[t]);
+  }
+}
+
+__device__ __forceinline__ unsigned add_pk(unsigned a, unsigned b) {
+  return pack_bf16x2(bf16lo(a) + bf16lo(b), bf16hi(a) + bf16hi(b));
+}
+__device__ __forceinline__ unsigned add3_pk(unsigned a, unsigned b, unsigned c) {
+  return pack_bf16x2(bf16lo(a) + bf16lo(b) + bf16lo(c), bf16hi(a) + bf16hi(b) + bf16hi(c));
+}
+
+__global__ __launch_bounds__(EW_THREADS)
+void add3_kernel(const unsigned short* __restrict__ a, const unsigned short* __restrict__ b,
+                 const unsigned short* __restrict__ c, unsigned short* __restrict__ y, int64_t n) {
+  const int64_t nvec = n >> 3;
+  const int64_t stride = (int64_t)gridDim.x * EW_THREADS;
+  for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < nvec; i += stride) {
+    const u32x4_t va = *reinterpret_cast<const u32x4_t*>(a + i * 8);
+    const u32x4_t vb = *reinterpret_cast<const u32x4_t*>(b + i * 8);
+    u32x4_t o;
+    if (c) {
+      const u32x4_t vc = *reinterpret_cast<const u32x4_t*>(c + i * 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = add3_pk(va[e], vb[e], vc[e]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = add_pk(va[e], vb[e]);
+    }
+    *reinterpret_cast<u32x4_t*>(y + i * 8) = o;
+  }
+  if (blockIdx.x == 0) {
+    const int64_t t = (nvec << 3) + threadIdx.x;
+    if (t < n) {
+      float s = bf16_bits_to_f32(a[t]) + bf16_bits_to_f32(b[t]);
+      if (c) s += bf16_bits_to_f32(c[t]);
+      y[t] = f32_to_bf16_bits(s);
+    }
+  }
+}
+
+__global__ __launch_bounds__(EW_THREADS)
+void relu_bwd_kernel(const unsigned short* __restrict__ dy, const unsigned short* __restrict__ y,
+                     unsigned short* __restrict__ dx, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * EW_THREADS;
+  for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n; i += stride) {
+    // sign/zero test on the bf16 pattern: y > 0  <=>  not negative and not +-0
+    const unsigned short yy = y[i];
+    dx[i] = (!(yy & 0x8000u) && (yy & 0x7fffu)) ? dy[i] : (unsigned short)0;
+  }
+}
+
+// mean over T: grid (B, ceil(d/512)); lane -> 8 columns, the 4 waves split T, LDS combine.
+__global__ __launch_bounds__(256)
+void meanpool_fwd_kernel(const unsigned short* __restrict__ x, unsigned short* __restrict__ y,
+                         int T, int d, int ldy) {
+  __shared__ float red[3][512];
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = (blockIdx.y * 64 + lane) * 8;
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (col < d) {
+    const unsigned short* p = x + (size_t)b * T * d + col;
+    for (int t = wave; t < T; t += 4) {
+      const u32x4_t w = *reinterpret_cast<const u32x4_t*>(p + (size_t)t * d);
+      s[0] += bf16lo(w[0]); s[1] += bf16hi(w[0]); s[2] += bf16lo(w[1]); s[3] += bf16hi(w[1]);
+      s[4] += bf16lo(w[2]); s[5] += bf16hi(w[2]); s[6] += bf16lo(w[3]); s[7] += bf16hi(w[3]);
+    }
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[wave - 1][lane * 8 + e] = s[e];
+  }
+  __syncthreads();
+  if (wave == 0 && col < d) {
+    const float inv = 1.f / (float)T;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = (s[e] + red[0][lane * 8 + e] + red[1][lane * 8 + e] + red[2][lane * 8 + e]) * inv;
+    u32x4_t o = {pack_bf16x2(s[0], s[1]), pack_bf16x2(s[2], s[3]), pack_bf16x2(s[4], s[5]), pack_bf16x2(s[6], s[7])};
+    *reinterpret_cast<u32x4_t*>(y + (size_t)b * ldy + col) = o;
+  }
+}
+
+__global__ __launch_bounds__(EW_THREADS)
+void meanpool_bwd_kernel(const unsigned short* __restrict__ dy, unsigned short* __restrict__ dx,
+                         int B, int T, int d, int lddy) {
+  const int dv = d >> 3;
+  const int64_t nvec = (int64_t)B * T * dv;
+  const float inv = 1.f / (float)T;
+  const int64_t stride = (int64_t)gridDim.x * EW_THREADS;
+  for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < nvec; i += stride) {
+    const int c = (int)(i % dv);
+    const int b = (int)(i / ((int64_t)T * dv));
+    const u32x4_t w = *reinterpret_cast<const u32x4_t*>(dy + (size_t)b * lddy + c * 8);
+    u32x4_t o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(bf16lo(w[e]) * inv, bf16hi(w[e]) * inv);
+    *reinterpret_cast<u32x4_t*>(dx + i * 8) = o;
+  }
+}
+
+// column sums: grid (ceil(N/512), row blocks); 4 waves split the block's rows; one atomic per column.
+constexpr int COLSUM_ROWS = 256;
+__global__ __launch_bounds__(256)
+void colsum_kernel(const unsigned short* __restrict__ x, float* __restrict__ out, int M, int N, int ldx) {
+  __shared__ float red[3][512];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = (blockIdx.x * 64 + lane) * 8;
+  const int r0 = blockIdx.y * COLSUM_ROWS;
+  const int r1 = min(M, r0 + COLSUM_ROWS);
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (col < N) {
+    for (int r = r0 + wave; r < r1; r += 4) {
+      const u32x4_t w = *reinterpret_cast<const u32x4_t*>(x + (size_t)r * ldx + col);
+      s[0] += bf16lo(w[0]); s[1] += bf16hi(w[0]); s[2] += bf16lo(w[1]); s[3] += bf16hi(w[1]);
+      s[4] += bf16lo(w[2]); s[5] += bf16hi(w[2]); s[6] += bf16lo(w[3]); s[7] += bf16hi(w[3]);
+    }
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[wave - 1][lane * 8 + e] = s[e];
+  }
+  __syncthreads();
+  if (wave == 0 && col < N) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      atomicAdd(out + col + e, s[e] + red[0][lane * 8 + e] + red[1][lane * 8 + e] + red[2][lane * 8 + e]);
+  }
+}
+
+}  // namespace
+
+#define EW_PTR_CHECK(name, cond) do { if (!(cond)) MMF_FAIL(MMF_E_ALIGN, name ": null or not 16-byte aligned pointer"); } while (0)
+
+extern "C" int mmf_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream) {
+  if (n <= 0) return MMF_OK;
+  EW_PTR_CHECK("mmf_cast_f32_to_bf16", src && dst && mmf_aligned16(src) && mmf_aligned16(dst));
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(ew_grid(n >> 3)), dim3(EW_THREADS), 0,
+                     static_cast<hipStream_t>(stream), src, static_cast<unsigned short*>(dst), n);
+  MMF_CHECK_LAUNCH("mmf_cast_f32_to_bf16");
+  return MMF_OK;
+}
+
+extern "C" int mmf_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream) {
+  if (n <= 0) return MMF_OK;
+  EW_PTR_CHECK("mmf_cast_bf16_to_f32", src && dst && mmf_aligned16(src) && mmf_aligned16(dst));
+  hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(ew_grid(n >> 3)), dim3(EW_THREADS), 0,
+                     static_cast<hipStream_t>(stream), static_cast<const unsigned short*>(src), dst, n);
+  MMF_CHECK_LAUNCH("mmf_cast_bf16_to_f32");
+  return MMF_OK;
+}
+
+extern "C" int mmf_add3_bf16(const void* a, const void* b, const void* c, void* y, int64_t n, void* stream) {
+  if (n <= 0) return MMF_OK;
+  EW_PTR_CHECK("mmf_add3_bf16", a && b && y && mmf_aligned16(a) && mmf_aligned16(b) && mmf_aligned16(y) &&
+               (!c || mmf_aligned16(c)));
+  hipLaunchKernelGGL(add3_kernel, dim3(ew_grid(n >> 3)), dim3(EW_THREADS), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const unsigned short*>(a), static_cast<const unsigned short*>(b),
+                     static_cast<const unsigned short*>(c), static_cast<unsigned short*>(y), n);
+  MMF_CHECK_LAUNCH("mmf_add3_bf16");
+  return MMF_OK;
+}
+
+extern "C" int mmf_relu_bwd_bf16(const void* dy, const void* y, void* dx, int64_t n, void* stream) {
+  if (n <= 0) return MMF_OK;
+  if (!dy || !y || !dx) MMF_FAIL(MMF_E_SHAPE, "mmf_relu_bwd_bf16: null pointer");
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3(ew_grid(n)), dim3(EW_THREADS), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const unsigned short*>(dy), static_cast<const unsigned short*>(y),
+                     static_cast<unsigned short*>(dx), n);
+  MMF_CHECK_LAUNCH("mmf_relu_bwd_bf16");
+  return MMF_OK;
+}
+
+extern "C" int mmf_meanpool_fwd(const void* x, void* y, int B, int T, int d, int ldy, void* stream) {
+  if (B <= 0 || T <= 0 || d <= 0 || (d & 7) || (ldy & 7) || ldy < d)
+    MMF_FAIL(MMF_E_SHAPE, "mmf_meanpool_fwd: B=%d T=%d d=%d ldy=%d (d, ldy multiples of 8)", B, T, d, ldy);
+  EW_PTR_CHECK("mmf_meanpool_fwd", x && y && mmf_aligned16(x) && mmf_aligned16(y));
+  hipLaunchKernelGGL(meanpool_fwd_kernel, dim3(B, (d + 511) / 512), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const unsigned short*>(x), static_cast<unsigned short*>(y), T, d, ldy);
+  MMF_CHECK_LAUNCH("mmf_meanpool_fwd");
+  return MMF_OK;
+}
+
+extern "C" int mmf_meanpool_bwd(const void* dy, void* dx, int B, int T, int d, int lddy, void* stream) {
+  if (B <= 0 || T <= 0 || d <= 0 || (d & 7) || (lddy & 7) || lddy < d)
+    MMF_FAIL(MMF_E_SHAPE, "mmf_meanpool_bwd: B=%d T=%d d=%d lddy=%d (d, lddy multiples of 8)", B, T, d, lddy);
+  EW_PTR_CHECK("mmf_meanpool_bwd", dy && dx && mmf_aligned16(dy) && mmf_aligned16(dx));
+  hipLaunchKernelGGL(meanpool_bwd_kernel, dim3(ew_grid((int64_t)B * T * (d >> 3))), dim3(EW_THREADS), 0,
+                     static_cast<hipStream_t>(stream), static_cast<const unsigned short*>(dy),
+                     static_cast<unsigned short*>(dx), B, T, d, lddy);
+  MMF_CHECK_LAUNCH("mmf_meanpool_bwd");
+  return MMF_OK;
+}
+
+extern "C" int mmf_colsum_bf16(const void* x, float* out, int M, int N, int ldx, void* stream) {
+  if (M <= 0 || N <= 0 || (N & 7) || (ldx & 7) || ldx < N)
+    MMF_FAIL(MMF_E_SHAPE, "mmf_colsum_bf16: M=%d N=%d ldx=%d (N, ldx multiples of 8)", M, N, ldx);
+  EW_PTR_CHECK("mmf_colsum_bf16", x && out && mmf_aligned16(x));
+  hipLaunchKernelGGL(colsum_kernel, dim3((N + 511) / 512, (M + COLSUM_ROWS - 1) / COLSUM_ROWS), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), static_cast<const unsigned short*>(x), out, M, N, ldx);
+  MMF_CHECK_LAUNCH("mmf_colsum_bf16");
+  return MMF_OK;
+}

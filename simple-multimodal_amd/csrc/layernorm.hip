@@ -1,0 +1,242 @@
+// LayerNorm forward / backward for the fusion path (nn.LayerNorm at models/fusion_layers.py:205,209).
+// HBM-bound: one wavefront owns one row (d <= 2048), 16-byte loads (8 bf16 per lane per chunk),
+// f32 statistics by wave butterfly reduction, no LDS in the forward.
+// Algorithmic bytes per row: forward 2 x 2d (x in, y out) + 8; backward 3 x 2d (x, dy in; dx out).
+#include "mmf_internal.h"
+
+namespace {
+
+constexpr int ROWS_PER_BLOCK = 4;      // 4 waves, one row each
+constexpr int MAX_CH = 4;              // 4 chunks x 64 lanes x 8 elements = 2048 columns
+
+struct LnArgs {
+  int nprob;
+  int d;
+  float eps;
+  int blk_start[MMF_LN_MAX_PROBLEMS + 1];
+  mmf_ln_problem p[MMF_LN_MAX_PROBLEMS];
+};
+
+__device__ __forceinline__ void unpack8(const u32x4_t& w, float (&f)[8]) {
+  f[0] = bf16lo(w[0]); f[1] = bf16hi(w[0]); f[2] = bf16lo(w[1]); f[3] = bf16hi(w[1]);
+  f[4] = bf16lo(w[2]); f[5] = bf16hi(w[2]); f[6] = bf16lo(w[3]); f[7] = bf16hi(w[3]);
+}
+__device__ __forceinline__ u32x4_t pack8(const float (&f)[8]) {
+  return u32x4_t{pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]),
+                 pack_bf16x2(f[6], f[7])};
+}
+
+template <int NCH>
+__global__ __launch_bounds__(256)
+void ln_fwd_kernel(const LnArgs a) {
+  int pi = 0;
+  while (pi + 1 < a.nprob && (int)blockIdx.x >= a.blk_start[pi + 1]) ++pi;
+  const mmf_ln_problem& P = a.p[pi];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = ((int)blockIdx.x - a.blk_start[pi]) * ROWS_PER_BLOCK + wave;
+  if (row >= P.rows) return;
+  const int d = a.d;
+  const unsigned short* x = static_cast<const unsigned short*>(P.x) + (size_t)row * d;
+  float v[NCH][8];
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int col = (c * 64 + lane) * 8;
+    if (col < d) {
+      unpack8(*reinterpret_cast<const u32x4_t*>(x + col), v[c]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += v[c][e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[c][e] = 0.f;
+    }
+  }
+  const float mean = wave_sum(s) / (float)d;
+  float q = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int col = (c * 64 + lane) * 8;
+    if (col < d) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float t = v[c][e] - mean; q += t * t; }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)d + a.eps);
+  unsigned short* y = static_cast<unsigned short*>(P.y) + (size_t)row * d;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int col = (c * 64 + lane) * 8;
+    if (col < d) {
+      const f32x4_t g0 = *reinterpret_cast<const f32x4_t*>(P.gamma + col);
+      const f32x4_t g1 = *reinterpret_cast<const f32x4_t*>(P.gamma + col + 4);
+      const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(P.beta + col);
+      const f32x4_t b1 = *reinterpret_cast<const f32x4_t*>(P.beta + col + 4);
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o[e] = (v[c][e] - mean) * rstd * g0[e] + b0[e];
+        o[e + 4] = (v[c][e + 4] - mean) * rstd * g1[e] + b1[e];
+      }
+      *reinterpret_cast<u32x4_t*>(y + col) = pack8(o);
+    }
+  }
+  if (lane == 0) { P.mean[row] = mean; P.rstd[row] = rstd; }
+}
+
+// Backward: a block owns a strided set of rows of ONE problem; each wave walks its rows, keeps the
+// dgamma/dbeta partial sums of its columns in registers, the 4 waves combine through LDS and the
+// block issues one f32 atomic per column (Guideline 12: reduce on chip, then one atomic per block).
+template <int NCH>
+__global__ __launch_bounds__(256)
+void ln_bwd_kernel(const LnArgs a) {
+  __shared__ float red[2][3][NCH * 512];          // [dgamma|dbeta][waves 1..3][column]
+  int pi = 0;
+  while (pi + 1 < a.nprob && (int)blockIdx.x >= a.blk_start[pi + 1]) ++pi;
+  const mmf_ln_problem& P = a.p[pi];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nblk = a.blk_start[pi + 1] - a.blk_start[pi];
+  const int d = a.d;
+  float dg[NCH][8], db[NCH][8];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { dg[c][e] = 0.f; db[c][e] = 0.f; }
+
+  for (int row = ((int)blockIdx.x - a.blk_start[pi]) * ROWS_PER_BLOCK + wave; row < P.rows;
+       row += nblk * ROWS_PER_BLOCK) {
+    const unsigned short* x = static_cast<const unsigned short*>(P.x) + (size_t)row * d;
+    const unsigned short* dy = static_cast<const unsigned short*>(P.dy) + (size_t)row * d;
+    const float mean = P.mean[row], rstd = P.rstd[row];
+    float xh[NCH][8], g[NCH][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int col = (c * 64 + lane) * 8;
+      if (col < d) {
+        float xv[8], dv[8];
+        unpack8(*reinterpret_cast<const u32x4_t*>(x + col), xv);
+        unpack8(*reinterpret_cast<const u32x4_t*>(dy + col), dv);
+        const f32x4_t g0 = *reinterpret_cast<const f32x4_t*>(P.gamma + col);
+        const f32x4_t g1 = *reinterpret_cast<const f32x4_t*>(P.gamma + col + 4);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float gam = e < 4 ? g0[e] : g1[e - 4];
+          xh[c][e] = (xv[e] - mean) * rstd;
+          g[c][e] = dv[e] * gam;
+          s1 += g[c][e];
+          s2 += g[c][e] * xh[c][e];
+          dg[c][e] += dv[e] * xh[c][e];
+          db[c][e] += dv[e];
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { xh[c][e] = 0.f; g[c][e] = 0.f; }
+      }
+    }
+    const float c1 = wave_sum(s1) / (float)d, c2 = wave_sum(s2) / (float)d;
+    unsigned short* dx = static_cast<unsigned short*>(P.dx) + (size_t)row * d;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int col = (c * 64 + lane) * 8;
+      if (col < d) {
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = rstd * (g[c][e] - c1 - xh[c][e] * c2);
+        *reinterpret_cast<u32x4_t*>(dx + col) = pack8(o);
+      }
+    }
+  }
+  // combine the 4 waves' column sums, then one atomic per column per block
+  if (wave > 0) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        red[0][wave - 1][(c * 64 + lane) * 8 + e] = dg[c][e];
+        red[1][wave - 1][(c * 64 + lane) * 8 + e] = db[c][e];
+      }
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int col = (c * 64 + lane) * 8;
+      if (col < d) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float sg = dg[c][e], sb = db[c][e];
+#pragma unroll
+          for (int w = 0; w < 3; ++w) { sg += red[0][w][col + e]; sb += red[1][w][col + e]; }
+          atomicAdd(P.dgamma + col + e, sg);
+          atomicAdd(P.dbeta + col + e, sb);
+        }
+      }
+    }
+  }
+}
+
+int check_common(const char* who, const mmf_ln_problem* p, int n, int d) {
+  if (!p || n <= 0 || n > MMF_LN_MAX_PROBLEMS) MMF_FAIL(MMF_E_SHAPE, "%s: num_problems=%d out of range", who, n);
+  if (d <= 0 || (d & 7) || d > MAX_CH * 512) MMF_FAIL(MMF_E_SHAPE, "%s: d=%d must be a multiple of 8, <= 2048", who, d);
+  return MMF_OK;
+}
+
+}  // namespace
+
+extern "C" int mmf_layernorm_fwd_grouped(const mmf_ln_problem* problems, int num_problems, int d,
+                                         float eps, void* stream) {
+  if (int rc = check_common("mmf_layernorm_fwd_grouped", problems, num_problems, d)) return rc;
+  LnArgs a; a.nprob = num_problems; a.d = d; a.eps = eps;
+  int total = 0;
+  for (int i = 0; i < num_problems; ++i) {
+    const mmf_ln_problem& p = problems[i];
+    if (p.rows <= 0 || !p.x || !p.y || !p.gamma || !p.beta || !p.mean || !p.rstd)
+      MMF_FAIL(MMF_E_SHAPE, "mmf_layernorm_fwd_grouped[%d]: null operand or rows=%d", i, p.rows);
+    if (!mmf_aligned16(p.x) || !mmf_aligned16(p.y) || !mmf_aligned16(p.gamma) || !mmf_aligned16(p.beta))
+      MMF_FAIL(MMF_E_ALIGN, "mmf_layernorm_fwd_grouped[%d]: pointers must be 16-byte aligned", i);
+    a.blk_start[i] = total;
+    total += (p.rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+    a.p[i] = p;
+  }
+  a.blk_start[num_problems] = total;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int nch = (d + 511) / 512;
+  switch (nch) {
+    case 1: hipLaunchKernelGGL(ln_fwd_kernel<1>, dim3(total), dim3(256), 0, s, a); break;
+    case 2: hipLaunchKernelGGL(ln_fwd_kernel<2>, dim3(total), dim3(256), 0, s, a); break;
+    case 3: hipLaunchKernelGGL(ln_fwd_kernel<3>, dim3(total), dim3(256), 0, s, a); break;
+    default: hipLaunchKernelGGL(ln_fwd_kernel<4>, dim3(total), dim3(256), 0, s, a); break;
+  }
+  MMF_CHECK_LAUNCH("mmf_layernorm_fwd_grouped");
+  return MMF_OK;
+}
+
+extern "C" int mmf_layernorm_bwd_grouped(const mmf_ln_problem* problems, int num_problems, int d,
+                                         void* stream) {
+  if (int rc = check_common("mmf_layernorm_bwd_grouped", problems, num_problems, d)) return rc;
+  LnArgs a; a.nprob = num_problems; a.d = d; a.eps = 0.f;
+  int total = 0;
+  for (int i = 0; i < num_problems; ++i) {
+    const mmf_ln_problem& p = problems[i];
+    if (p.rows <= 0 || !p.x || !p.dy || !p.dx || !p.gamma || !p.mean || !p.rstd || !p.dgamma || !p.dbeta)
+      MMF_FAIL(MMF_E_SHAPE, "mmf_layernorm_bwd_grouped[%d]: null operand or rows=%d", i, p.rows);
+    if (!mmf_aligned16(p.x) || !mmf_aligned16(p.dy) || !mmf_aligned16(p.dx) || !mmf_aligned16(p.gamma))
+      MMF_FAIL(MMF_E_ALIGN, "mmf_layernorm_bwd_grouped[%d]: pointers must be 16-byte aligned", i);
+    a.blk_start[i] = total;
+    int nb = (p.rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+    if (nb > 256) nb = 256;                       // <= 256 blocks x d atomics per problem
+    total += nb;
+    a.p[i] = p;
+  }
+  a.blk_start[num_problems] = total;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int nch = (d + 511) / 512;
+  switch (nch) {
+    case 1: hipLaunchKernelGGL(ln_bwd_kernel<1>, dim3(total), dim3(256), 0, s, a); break;
+    case 2: hipLaunchKernelGGL(ln_bwd_kernel<2>, dim3(total), dim3(256), 0, s, a); break;
+    case 3: hipLaunchKernelGGL(ln_bwd_kernel<3>, dim3(total), dim3(256), 0, s, a); break;
+    default: hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(total), dim3(256), 0, s, a); break;
+  }
+  MMF_CHECK_LAUNCH("mmf_layernorm_bwd_grouped");
+  return MMF_OK;
+}

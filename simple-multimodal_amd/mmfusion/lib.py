@@ -1,0 +1,120 @@
+"""ctypes binding of ``libmmfusion.so`` (C ABI: ``include/mmfusion.h``).
+
+The library is the product: there is no CPU or eager fallback.  ``load()`` raises if the shared
+object is missing, and every wrapper raises ``RuntimeError(mmf_last_error())`` on a negative
+return code.  Wrappers take raw device pointers (``tensor.data_ptr()``) and enqueue on the HIP
+stream that torch currently uses, so launches are ordered with torch's own work and can be
+captured by ``torch.cuda.graph``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional, Sequence
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmmfusion.so")
+
+GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
+EPI_BIAS, EPI_RELU, EPI_MASK_AUX, EPI_ADD_AUX, EPI_ACCUM = 1, 2, 4, 8, 16
+GEMM_MAX_PROBLEMS, ATTN_MAX_PROBLEMS, LN_MAX_PROBLEMS = 24, 12, 8
+
+# every symbol include/mmfusion.h declares (tests check the .so exports all of them)
+SYMBOLS = (
+    "mmf_version", "mmf_last_error", "mmf_device_cu_count", "mmf_gemm_grouped",
+    "mmf_attn_fwd_grouped", "mmf_attn_bwd_grouped", "mmf_layernorm_fwd_grouped",
+    "mmf_layernorm_bwd_grouped", "mmf_cast_f32_to_bf16", "mmf_cast_bf16_to_f32", "mmf_add3_bf16",
+    "mmf_meanpool_fwd", "mmf_meanpool_bwd", "mmf_colsum_bf16", "mmf_relu_bwd_bf16",
+)
+
+
+class GemmProblem(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p), ("bias", C.c_void_p),
+                ("aux", C.c_void_p), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+                ("lda", C.c_int32), ("ldb", C.c_int32), ("ldc", C.c_int32), ("ldaux", C.c_int32)]
+
+
+class AttnProblem(C.Structure):
+    _fields_ = [("Q", C.c_void_p), ("K", C.c_void_p), ("V", C.c_void_p), ("O", C.c_void_p),
+                ("LSE", C.c_void_p), ("dO", C.c_void_p), ("delta", C.c_void_p), ("dQ", C.c_void_p),
+                ("dK", C.c_void_p), ("dV", C.c_void_p), ("B", C.c_int32), ("H", C.c_int32),
+                ("Tq", C.c_int32), ("Tk", C.c_int32), ("ldq", C.c_int32), ("ldk", C.c_int32),
+                ("ldv", C.c_int32), ("ldo", C.c_int32)]
+
+
+class LnProblem(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
+                ("mean", C.c_void_p), ("rstd", C.c_void_p), ("dy", C.c_void_p), ("dx", C.c_void_p),
+                ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("rows", C.c_int32)]
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Load libmmfusion.so (built by ``__graft_entry__.build()`` / ``make -C csrc``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the MI355X fusion path has no fallback. Build it with "
+            f"`python -c 'import __graft_entry__ as g; g.build()'` or `make -C simple-multimodal_amd/csrc`.")
+    lib = C.CDLL(LIB_PATH)
+    lib.mmf_last_error.restype = C.c_char_p
+    lib.mmf_version.restype = C.c_int
+    vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
+    lib.mmf_gemm_grouped.argtypes = [C.POINTER(GemmProblem), i32, i32, i32, i32, vp]
+    lib.mmf_attn_fwd_grouped.argtypes = [C.POINTER(AttnProblem), i32, i32, f32, vp]
+    lib.mmf_attn_bwd_grouped.argtypes = [C.POINTER(AttnProblem), i32, i32, f32, vp]
+    lib.mmf_layernorm_fwd_grouped.argtypes = [C.POINTER(LnProblem), i32, i32, f32, vp]
+    lib.mmf_layernorm_bwd_grouped.argtypes = [C.POINTER(LnProblem), i32, i32, vp]
+    lib.mmf_cast_f32_to_bf16.argtypes = [vp, vp, i64, vp]
+    lib.mmf_cast_bf16_to_f32.argtypes = [vp, vp, i64, vp]
+    lib.mmf_add3_bf16.argtypes = [vp, vp, vp, vp, i64, vp]
+    lib.mmf_meanpool_fwd.argtypes = [vp, vp, i32, i32, i32, i32, vp]
+    lib.mmf_meanpool_bwd.argtypes = [vp, vp, i32, i32, i32, i32, vp]
+    lib.mmf_colsum_bf16.argtypes = [vp, vp, i32, i32, i32, vp]
+    lib.mmf_relu_bwd_bf16.argtypes = [vp, vp, vp, i64, vp]
+    for name in SYMBOLS:
+        getattr(lib, name)          # AttributeError here = header and .so disagree
+    if lib.mmf_version() != 1:
+        raise RuntimeError(f"libmmfusion ABI version {lib.mmf_version()} != 1")
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise RuntimeError(f"libmmfusion error {rc}: {load().mmf_last_error().decode()}")
+
+
+def stream_ptr() -> int:
+    """The HIP stream torch is currently enqueuing on (raw hipStream_t)."""
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def gemm_grouped(problems: Sequence[GemmProblem], layout: int, epilogue: int, out_f32: bool) -> None:
+    arr = (GemmProblem * len(problems))(*problems)
+    check(load().mmf_gemm_grouped(arr, len(problems), layout, epilogue, int(out_f32), stream_ptr()))
+
+
+def attn_fwd_grouped(problems: Sequence[AttnProblem], head_dim: int, scale: float) -> None:
+    arr = (AttnProblem * len(problems))(*problems)
+    check(load().mmf_attn_fwd_grouped(arr, len(problems), head_dim, scale, stream_ptr()))
+
+
+def attn_bwd_grouped(problems: Sequence[AttnProblem], head_dim: int, scale: float) -> None:
+    arr = (AttnProblem * len(problems))(*problems)
+    check(load().mmf_attn_bwd_grouped(arr, len(problems), head_dim, scale, stream_ptr()))
+
+
+def layernorm_fwd_grouped(problems: Sequence[LnProblem], d: int, eps: float) -> None:
+    arr = (LnProblem * len(problems))(*problems)
+    check(load().mmf_layernorm_fwd_grouped(arr, len(problems), d, eps, stream_ptr()))
+
+
+def layernorm_bwd_grouped(problems: Sequence[LnProblem], d: int) -> None:
+    arr = (LnProblem * len(problems))(*problems)
+    check(load().mmf_layernorm_bwd_grouped(arr, len(problems), d, stream_ptr()))

@@ -1,0 +1,462 @@
+"""Autograd wrappers around the HIP kernels of ``libmmfusion.so``.
+
+Data layout: activations are bf16, row-major 2-D ``(rows, features)`` with
+``rows = B*T``; parameters are fp32 masters living in a flat arena (``mmfusion.arena``) with a
+bf16 shadow copy used by the MFMA kernels; weight/bias/LayerNorm gradients are accumulated by
+the kernels **directly into ``param.grad``** (an fp32 view of the flat gradient arena, the buffer
+RCCL all-reduces), so the Functions return ``None`` for parameters.
+
+Every op is *grouped*: it takes a list of independent problems and issues one launch for all of
+them (the six cross-modal blocks of MulT, reference models/fusion_layers.py:146-153, are mutually
+independent), which is what fills 256 CUs with these small per-block shapes.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import lib
+from .lib import (AttnProblem, GemmProblem, LnProblem, EPI_ACCUM, EPI_ADD_AUX, EPI_BIAS,
+                  EPI_MASK_AUX, EPI_RELU, GEMM_NN, GEMM_NT, GEMM_TN)
+
+BF16 = torch.bfloat16
+
+
+# --------------------------------------------------------------------------------------------
+# parameter references
+# --------------------------------------------------------------------------------------------
+@dataclass
+class W:
+    """Rows [r0, r1) of a (out, in) weight parameter: fp32 master + bf16 shadow."""
+    p: torch.nn.Parameter
+    r0: int = 0
+    r1: Optional[int] = None
+
+    def rows(self) -> Tuple[int, int]:
+        return self.r0, (self.p.shape[0] if self.r1 is None else self.r1)
+
+    @property
+    def w16(self) -> torch.Tensor:
+        s = getattr(self.p, "_mmf_bf16", None)
+        if s is None:
+            raise RuntimeError("parameter is not arena-managed: call mmfusion.arena.ensure(module) first")
+        a, b = self.rows()
+        return s[a:b]
+
+    @property
+    def grad(self) -> torch.Tensor:
+        g = self.p.grad
+        if g is None or g.dtype != torch.float32 or not g.is_contiguous():
+            raise RuntimeError("parameter has no fp32 arena gradient: call mmfusion.arena.ensure(module)")
+        a, b = self.rows()
+        return g[a:b]
+
+    @property
+    def master(self) -> torch.Tensor:
+        a, b = self.rows()
+        return self.p.detach()[a:b]
+
+
+def _ld(t: torch.Tensor) -> int:
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise ValueError(f"expected a 2-D row-major (possibly row-strided) tensor, got {tuple(t.shape)} strides {t.stride()}")
+    return t.stride(0)
+
+
+def _req(t: torch.Tensor, dtype) -> None:
+    if not t.is_cuda:
+        raise RuntimeError("mmfusion ops run on the GPU only (no CPU fallback)")
+    if t.dtype != dtype:
+        raise TypeError(f"expected {dtype}, got {t.dtype}")
+
+
+# --------------------------------------------------------------------------------------------
+# raw (non-autograd) helpers
+# --------------------------------------------------------------------------------------------
+def cast_to_bf16(x: torch.Tensor) -> torch.Tensor:
+    _req(x, torch.float32)
+    x = x.contiguous()
+    y = torch.empty(x.shape, dtype=BF16, device=x.device)
+    lib.check(lib.load().mmf_cast_f32_to_bf16(x.data_ptr(), y.data_ptr(), x.numel(), lib.stream_ptr()))
+    return y
+
+
+def cast_to_f32(x: torch.Tensor) -> torch.Tensor:
+    _req(x, BF16)
+    x = x.contiguous()
+    y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    lib.check(lib.load().mmf_cast_bf16_to_f32(x.data_ptr(), y.data_ptr(), x.numel(), lib.stream_ptr()))
+    return y
+
+
+def gemm(layout: int, A: torch.Tensor, Bm: torch.Tensor, C: torch.Tensor, *, bias=None, aux=None,
+         epilogue: int = 0) -> None:
+    """Single-problem convenience over gemm_group (shapes are taken from C and the layout)."""
+    gemm_group(layout, [(A, Bm, C, bias, aux)], epilogue)
+
+
+def gemm_group(layout: int, probs: Sequence[tuple], epilogue: int) -> None:
+    """probs: (A, B, C, bias|None, aux|None) tensors; M,N from C; K from A."""
+    out_f32 = probs[0][2].dtype == torch.float32
+    ps: List[GemmProblem] = []
+    for (A, Bm, Cm, bias, aux) in probs:
+        _req(A, BF16), _req(Bm, BF16)
+        M, N = Cm.shape
+        K = A.shape[0] if layout == GEMM_TN else A.shape[1]
+        if layout == GEMM_NT:
+            ok = A.shape == (M, K) and Bm.shape == (N, K)
+        elif layout == GEMM_NN:
+            ok = A.shape == (M, K) and Bm.shape == (K, N)
+        else:
+            ok = A.shape == (K, M) and Bm.shape == (K, N)
+        if not ok or (Cm.dtype == torch.float32) != out_f32:
+            raise ValueError(f"gemm layout {layout}: A{tuple(A.shape)} B{tuple(Bm.shape)} C{tuple(Cm.shape)}")
+        if aux is not None and tuple(aux.shape) != (M, N):
+            raise ValueError("aux must match C")
+        if bias is not None:
+            _req(bias, torch.float32)
+            if bias.numel() != N or not bias.is_contiguous():
+                raise ValueError("bias must be contiguous [N]")
+        ps.append(GemmProblem(A.data_ptr(), Bm.data_ptr(), Cm.data_ptr(),
+                              bias.data_ptr() if bias is not None else None,
+                              aux.data_ptr() if aux is not None else None,
+                              M, N, K, _ld(A), _ld(Bm), _ld(Cm), _ld(aux) if aux is not None else 0))
+    for i in range(0, len(ps), lib.GEMM_MAX_PROBLEMS):
+        lib.gemm_grouped(ps[i:i + lib.GEMM_MAX_PROBLEMS], layout, epilogue, out_f32)
+
+
+# --------------------------------------------------------------------------------------------
+# dtype boundary
+# --------------------------------------------------------------------------------------------
+class _ToBF16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return cast_to_bf16(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return cast_to_f32(g)
+
+
+class _ToF32(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return cast_to_f32(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return cast_to_bf16(g)
+
+
+def to_bf16(x: torch.Tensor) -> torch.Tensor:
+    return x if x.dtype == BF16 else _ToBF16.apply(x)
+
+
+def to_f32(x: torch.Tensor) -> torch.Tensor:
+    return x if x.dtype == torch.float32 else _ToF32.apply(x)
+
+
+# --------------------------------------------------------------------------------------------
+# grouped Linear:  y_i = act(x_i W_i^T + b_i) (+ residual_i)
+# --------------------------------------------------------------------------------------------
+@dataclass
+class LinearSpec:
+    w: W
+    b: Optional[W] = None          # bias parameter rows [r0, r1) (1-D parameter)
+    relu: bool = False
+    has_residual: bool = False
+
+
+class _GroupedLinear(torch.autograd.Function):
+    """tensors = [x_0, res_0|None, w_0.p, b_0.p|None, x_1, ...]; returns one output per spec."""
+
+    @staticmethod
+    def forward(ctx, specs: List[LinearSpec], out_f32: bool, *tensors):
+        n = len(specs)
+        relu = specs[0].relu
+        has_bias = specs[0].b is not None
+        has_res = specs[0].has_residual
+        if any(s.relu != relu or (s.b is not None) != has_bias or s.has_residual != has_res for s in specs):
+            raise ValueError("a linear group must share one epilogue")
+        xs, ress, outs, probs = [], [], [], []
+        for i, s in enumerate(specs):
+            x, res = tensors[4 * i], tensors[4 * i + 1]
+            _req(x, BF16)
+            w16 = s.w.w16
+            bias = s.b.master if has_bias else None
+            y = torch.empty((x.shape[0], w16.shape[0]), dtype=torch.float32 if out_f32 else BF16, device=x.device)
+            probs.append((x, w16, y, bias, res))
+            xs.append(x), ress.append(res), outs.append(y)
+        epi = (EPI_BIAS if has_bias else 0) | (EPI_RELU if relu else 0) | (EPI_ADD_AUX if has_res else 0)
+        gemm_group(GEMM_NT, probs, epi)
+        ctx.specs, ctx.out_f32 = specs, out_f32
+        ctx.save_for_backward(*xs, *(outs if relu else []))
+        ctx.x_needs = [tensors[4 * i].requires_grad for i in range(n)]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gys):
+        specs = ctx.specs
+        n = len(specs)
+        saved = ctx.saved_tensors
+        xs = saved[:n]
+        ys = saved[n:] if specs[0].relu else None
+        L = lib.load()
+        st = lib.stream_ptr()
+        dys = []
+        for i, g in enumerate(gys):
+            if g is None:
+                dys.append(None)
+                continue
+            g = g.contiguous()
+            if g.dtype != BF16:
+                g = cast_to_bf16(g)
+            if specs[0].relu:                      # dz = dy * (y > 0)
+                y = ys[i] if ys[i].dtype == BF16 else cast_to_bf16(ys[i])
+                dz = torch.empty_like(g)
+                lib.check(L.mmf_relu_bwd_bf16(g.data_ptr(), y.data_ptr(), dz.data_ptr(), g.numel(), st))
+                g = dz
+            dys.append(g)
+        dgrad, wgrad = [], []
+        grads: List[Optional[torch.Tensor]] = [None] * (4 * n)
+        for i, s in enumerate(specs):
+            g = dys[i]
+            if g is None:
+                continue
+            if ctx.x_needs[i]:
+                dx = torch.empty(xs[i].shape, dtype=BF16, device=g.device)
+                dgrad.append((g, s.w.w16, dx, None, None))
+                grads[4 * i] = dx
+            wgrad.append((g, xs[i], s.w.grad, None, None))
+            if s.b is not None:
+                lib.check(L.mmf_colsum_bf16(g.data_ptr(), s.b.grad.data_ptr(), g.shape[0], g.shape[1], _ld(g), st))
+            if s.has_residual:
+                grads[4 * i + 1] = g
+        if dgrad:
+            gemm_group(GEMM_NN, dgrad, 0)
+        if wgrad:
+            gemm_group(GEMM_TN, wgrad, EPI_ACCUM)
+        return (None, None, *grads)
+
+
+def linear_group(items: Sequence[tuple], out_f32: bool = False) -> List[torch.Tensor]:
+    """items: (x_bf16 [M,K], LinearSpec, residual_bf16|None).  One NT launch for the group."""
+    specs, tensors = [], []
+    for x, spec, res in items:
+        spec.has_residual = res is not None
+        specs.append(spec)
+        tensors += [x, res, spec.w.p, spec.b.p if spec.b is not None else None]
+    return list(_GroupedLinear.apply(specs, out_f32, *tensors))
+
+
+def linear(x: torch.Tensor, w: W, b: Optional[W] = None, relu: bool = False,
+           residual: Optional[torch.Tensor] = None, out_f32: bool = False) -> torch.Tensor:
+    return linear_group([(x, LinearSpec(w, b, relu), residual)], out_f32)[0]
+
+
+# --------------------------------------------------------------------------------------------
+# grouped LayerNorm
+# --------------------------------------------------------------------------------------------
+class _GroupedLayerNorm(torch.autograd.Function):
+    """tensors = [x_0, gamma_0, beta_0, x_1, ...]"""
+
+    @staticmethod
+    def forward(ctx, eps: float, *tensors):
+        n = len(tensors) // 3
+        d = tensors[0].shape[-1]
+        outs, stats, probs = [], [], []
+        for i in range(n):
+            x, g, b = tensors[3 * i:3 * i + 3]
+            _req(x, BF16)
+            x = x.contiguous()
+            rows = x.numel() // d
+            y = torch.empty_like(x)
+            st = torch.empty((2, rows), dtype=torch.float32, device=x.device)
+            probs.append(LnProblem(x.data_ptr(), y.data_ptr(), g.data_ptr(), b.data_ptr(), st[0].data_ptr(),
+                                   st[1].data_ptr(), None, None, None, None, rows))
+            outs.append(y), stats.append(st)
+        for i in range(0, n, lib.LN_MAX_PROBLEMS):
+            lib.layernorm_fwd_grouped(probs[i:i + lib.LN_MAX_PROBLEMS], d, eps)
+        ctx.n, ctx.d = n, d
+        ctx.params = [(tensors[3 * i + 1], tensors[3 * i + 2]) for i in range(n)]
+        ctx.save_for_backward(*[tensors[3 * i] for i in range(n)], *stats)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gys):
+        n, d = ctx.n, ctx.d
+        xs, stats = ctx.saved_tensors[:n], ctx.saved_tensors[n:]
+        grads: List[Optional[torch.Tensor]] = [None] * (3 * n)
+        probs = []
+        for i, g in enumerate(gys):
+            if g is None:
+                continue
+            g = g.contiguous()
+            x = xs[i].contiguous()
+            gamma, beta = ctx.params[i]
+            if gamma.grad is None or beta.grad is None:
+                raise RuntimeError("LayerNorm parameters have no arena gradient")
+            dx = torch.empty_like(x)
+            rows = x.numel() // d
+            probs.append(LnProblem(x.data_ptr(), None, gamma.data_ptr(), None, stats[i][0].data_ptr(),
+                                   stats[i][1].data_ptr(), g.data_ptr(), dx.data_ptr(),
+                                   gamma.grad.data_ptr(), beta.grad.data_ptr(), rows))
+            grads[3 * i] = dx
+        for i in range(0, len(probs), lib.LN_MAX_PROBLEMS):
+            lib.layernorm_bwd_grouped(probs[i:i + lib.LN_MAX_PROBLEMS], d)
+        return (None, *grads)
+
+
+def layernorm_group(items: Sequence[tuple], eps: float = 1e-5) -> List[torch.Tensor]:
+    """items: (x_bf16 [..., d], gamma_param, beta_param)."""
+    flat = []
+    for x, g, b in items:
+        flat += [x, g, b]
+    return list(_GroupedLayerNorm.apply(eps, *flat))
+
+
+# --------------------------------------------------------------------------------------------
+# grouped fused attention
+# --------------------------------------------------------------------------------------------
+@dataclass
+class AttnSpec:
+    """One attention problem.  q/k/v are (source index, first column) into the `srcs` list of 2-D
+    bf16 buffers (rows = B*T, row-major); heads are laid out as consecutive head_dim column groups."""
+    B: int
+    Tq: int
+    Tk: int
+    q: Tuple[int, int]
+    k: Tuple[int, int]
+    v: Tuple[int, int]
+
+
+class _GroupedAttention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, specs: List[AttnSpec], H: int, dh: int, *srcs):
+        scale = 1.0 / math.sqrt(dh)
+        d = H * dh
+        outs, lses, probs = [], [], []
+        for s in specs:
+            for (si, col), T in ((s.q, s.Tq), (s.k, s.Tk), (s.v, s.Tk)):
+                t = srcs[si]
+                _req(t, BF16)
+                if t.dim() != 2 or not t.is_contiguous() or t.shape[0] != s.B * T or col + d > t.shape[1]:
+                    raise ValueError(f"attention source {si}: shape {tuple(t.shape)} does not hold B*T={s.B * T} rows x {d} columns at {col}")
+            dev = srcs[0].device
+            o = torch.empty((s.B * s.Tq, d), dtype=BF16, device=dev)
+            lse = torch.empty((s.B * H * s.Tq,), dtype=torch.float32, device=dev)
+            qs, ks, vs = srcs[s.q[0]], srcs[s.k[0]], srcs[s.v[0]]
+            probs.append(AttnProblem(qs.data_ptr() + 2 * s.q[1], ks.data_ptr() + 2 * s.k[1], vs.data_ptr() + 2 * s.v[1],
+                                     o.data_ptr(), lse.data_ptr(), None, None, None, None, None,
+                                     s.B, H, s.Tq, s.Tk, qs.shape[1], ks.shape[1], vs.shape[1], d))
+            outs.append(o), lses.append(lse)
+        for i in range(0, len(probs), lib.ATTN_MAX_PROBLEMS):
+            lib.attn_fwd_grouped(probs[i:i + lib.ATTN_MAX_PROBLEMS], dh, scale)
+        ctx.specs, ctx.H, ctx.dh, ctx.nsrc = specs, H, dh, len(srcs)
+        ctx.save_for_backward(*srcs, *outs, *lses)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gos):
+        specs, H, dh, ns = ctx.specs, ctx.H, ctx.dh, ctx.nsrc
+        n = len(specs)
+        d = H * dh
+        srcs = ctx.saved_tensors[:ns]
+        outs = ctx.saved_tensors[ns:ns + n]
+        lses = ctx.saved_tensors[ns + n:]
+        # one gradient buffer per source; zero-filled only when some column range is not covered
+        covered = [set() for _ in range(ns)]
+        for s, g in zip(specs, gos):
+            if g is None:
+                continue
+            for si, col in (s.q, s.k, s.v):
+                covered[si].add(col)
+        gsrc: List[Optional[torch.Tensor]] = []
+        for si, t in enumerate(srcs):
+            if not covered[si]:
+                gsrc.append(None)
+                continue
+            full = len(covered[si]) * d == t.shape[1]
+            gsrc.append(torch.empty_like(t) if full else torch.zeros_like(t))
+        probs = []
+        for i, (s, g) in enumerate(zip(specs, gos)):
+            if g is None:
+                continue
+            g = g.contiguous()
+            delta = torch.empty_like(lses[i])
+            qs, ks, vs = srcs[s.q[0]], srcs[s.k[0]], srcs[s.v[0]]
+            probs.append(AttnProblem(qs.data_ptr() + 2 * s.q[1], ks.data_ptr() + 2 * s.k[1], vs.data_ptr() + 2 * s.v[1],
+                                     outs[i].data_ptr(), lses[i].data_ptr(), g.data_ptr(), delta.data_ptr(),
+                                     gsrc[s.q[0]].data_ptr() + 2 * s.q[1], gsrc[s.k[0]].data_ptr() + 2 * s.k[1],
+                                     gsrc[s.v[0]].data_ptr() + 2 * s.v[1],
+                                     s.B, H, s.Tq, s.Tk, qs.shape[1], ks.shape[1], vs.shape[1], d))
+        for i in range(0, len(probs), lib.ATTN_MAX_PROBLEMS):
+            lib.attn_bwd_grouped(probs[i:i + lib.ATTN_MAX_PROBLEMS], dh, 1.0 / math.sqrt(dh))
+        return (None, None, None, *gsrc)
+
+
+def attention_group(specs: List[AttnSpec], H: int, dh: int, srcs: Sequence[torch.Tensor]) -> List[torch.Tensor]:
+    """Each (source, column) pair may be the k or v of several problems only if those problems'
+    gradients are wanted separately — within one call every (source, column) range must be
+    written by at most one problem's dK/dV (true for MulT: each block has its own K/V projection)."""
+    return list(_GroupedAttention.apply(specs, H, dh, *srcs))
+
+
+# --------------------------------------------------------------------------------------------
+# elementwise / pooling
+# --------------------------------------------------------------------------------------------
+class _Add3(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, c):
+        _req(a, BF16)
+        a, b = a.contiguous(), b.contiguous()
+        c = c.contiguous() if c is not None else None
+        y = torch.empty_like(a)
+        lib.check(lib.load().mmf_add3_bf16(a.data_ptr(), b.data_ptr(), c.data_ptr() if c is not None else None,
+                                           y.data_ptr(), a.numel(), lib.stream_ptr()))
+        ctx.has_c = c is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g, (g if ctx.has_c else None)
+
+
+def add3(a, b, c=None):
+    return _Add3.apply(a, b, c)
+
+
+class _MeanPoolCat(torch.autograd.Function):
+    """xs: (B, T_i, d) bf16 -> (B, n*d) bf16 = cat_i mean_t x_i  (fusion_layers.py:166-171)."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        B, _, d = xs[0].shape
+        n = len(xs)
+        y = torch.empty((B, n * d), dtype=BF16, device=xs[0].device)
+        L, st = lib.load(), lib.stream_ptr()
+        for i, x in enumerate(xs):
+            _req(x, BF16)
+            x = x.contiguous()
+            lib.check(L.mmf_meanpool_fwd(x.data_ptr(), y.data_ptr() + 2 * i * d, B, x.shape[1], d, n * d, st))
+        ctx.shapes = [tuple(x.shape) for x in xs]
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        L, st = lib.load(), lib.stream_ptr()
+        n = len(ctx.shapes)
+        out = []
+        for i, (B, T, d) in enumerate(ctx.shapes):
+            dx = torch.empty((B, T, d), dtype=BF16, device=g.device)
+            lib.check(L.mmf_meanpool_bwd(g.data_ptr() + 2 * i * d, dx.data_ptr(), B, T, d, n * d, st))
+            out.append(dx)
+        return tuple(out)
+
+
+def meanpool_cat(xs: Sequence[torch.Tensor]) -> torch.Tensor:
+    return _MeanPoolCat.apply(*xs)

@@ -1,0 +1,437 @@
+"""MI355X-native fusion layers — drop-in for the reference's ``models/fusion_layers.py``.
+
+Same class names, constructor ``(config)``, forward signatures, return keys and
+``state_dict()`` keys/shapes as the reference (citations: reference file ``models/fusion_layers.py``),
+but every dense contraction, attention, LayerNorm, residual sum and pooling runs in the
+hand-written gfx950 kernels of ``libmmfusion.so`` through ``mmfusion.ops``:
+
+  * parameters stay fp32 ``nn.Parameter``s (reference checkpoints load), re-homed into a flat
+    arena with a bf16 shadow for the MFMA kernels and an fp32 gradient arena (``mmfusion.arena``);
+  * activations are bf16 ``(B*T, d)`` row-major; fp32 accumulation / softmax / LN statistics;
+  * independent sub-blocks are issued as grouped launches (six cross-modal blocks -> one launch
+    per stage instead of six).
+
+There is no CPU path: calling these modules with CPU tensors raises.  Dropout (reference
+``fusion_dropout``) must be 0 or the module in eval mode for parity; see ``_check_dropout``.
+"""
+from __future__ import annotations
+
+import math
+import warnings
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from mmfusion import arena as _arena
+from mmfusion import ops
+from mmfusion.ops import AttnSpec, LinearSpec, W
+
+_depth = 0          # >0 while inside an outer fusion forward: the arena was already ensured
+
+
+class _FusionBase(nn.Module):
+    """Arena handling shared by all fusion modules."""
+
+    def _enter(self):
+        global _depth
+        if _depth == 0:
+            _arena.ensure(self, refresh=self.training)
+        _depth += 1
+
+    @staticmethod
+    def _exit():
+        global _depth
+        _depth -= 1
+
+    def __call__(self, *args, **kwargs):
+        self._enter()
+        try:
+            return super().__call__(*args, **kwargs)
+        finally:
+            self._exit()
+
+
+_warned_dropout = False
+
+
+def _check_dropout(module: nn.Module, p: float) -> None:
+    """The reference applies dropout(p) to attention probabilities, FFN hidden and fusion outputs.
+    The HIP path has no in-kernel RNG yet: p > 0 in training mode is treated as identity, loudly."""
+    global _warned_dropout
+    if module.training and p > 0.0 and not _warned_dropout:
+        _warned_dropout = True
+        warnings.warn("mmfusion: fusion_dropout > 0 in training mode is not applied by the HIP path "
+                      "(treated as p = 0); set config.fusion_dropout = 0 for parity runs.")
+
+
+def _as_rows(x: torch.Tensor) -> torch.Tensor:
+    """(B, T, d) or (B, d), fp32 or bf16 -> contiguous bf16 (B*T, d)."""
+    if not x.is_cuda:
+        raise RuntimeError("mmfusion fusion layers run on the GPU only (no CPU fallback)")
+    return ops.to_bf16(x.contiguous()).reshape(-1, x.shape[-1])
+
+
+def _lin(layer: nn.Linear, relu: bool = False) -> LinearSpec:
+    return LinearSpec(W(layer.weight), W(layer.bias) if layer.bias is not None else None, relu)
+
+
+class _MHAParams(nn.Module):
+    """Parameter container with nn.MultiheadAttention's names, shapes and initialisation
+    (packed in_proj_weight (3d, d) xavier-uniform, zero biases; torch activation.py)."""
+
+    def __init__(self, embed_dim: int, num_heads: int):
+        super().__init__()
+        if embed_dim % num_heads:
+            raise ValueError("embed_dim must be divisible by num_heads")
+        self.embed_dim, self.num_heads, self.head_dim = embed_dim, num_heads, embed_dim // num_heads
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * embed_dim, embed_dim))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * embed_dim))
+        self.out_proj = nn.Linear(embed_dim, embed_dim)
+        nn.init.xavier_uniform_(self.in_proj_weight)
+        nn.init.zeros_(self.out_proj.bias)
+
+    def q_spec(self) -> LinearSpec:
+        d = self.embed_dim
+        return LinearSpec(W(self.in_proj_weight, 0, d), W(self.in_proj_bias, 0, d))
+
+    def kv_spec(self) -> LinearSpec:
+        d = self.embed_dim
+        return LinearSpec(W(self.in_proj_weight, d, 3 * d), W(self.in_proj_bias, d, 3 * d))
+
+    def qkv_spec(self) -> LinearSpec:
+        return LinearSpec(W(self.in_proj_weight), W(self.in_proj_bias))
+
+
+# ------------------------------------------------------------------------------------------------
+# grouped building blocks
+# ------------------------------------------------------------------------------------------------
+def _cross_blocks(blocks: Sequence["CrossModalTransformer"], qs: Sequence[torch.Tensor],
+                  kvs: Sequence[torch.Tensor], B: int, Tqs: Sequence[int], Tks: Sequence[int]
+                  ) -> List[torch.Tensor]:
+    """n independent CrossModalTransformer blocks (reference :202-211), one launch per stage.
+    qs[i]: bf16 (B*Tq_i, d); kvs[i]: bf16 (B*Tk_i, d)."""
+    mp0 = blocks[0].attention
+    d, H, dh = mp0.embed_dim, mp0.num_heads, mp0.head_dim
+    items = []
+    for blk, q, kv in zip(blocks, qs, kvs):
+        items.append((q, blk.attention.q_spec(), None))
+        items.append((kv, blk.attention.kv_spec(), None))
+    proj = ops.linear_group(items)                                   # [Q0, KV0, Q1, KV1, ...]
+    specs = [AttnSpec(B, Tqs[i], Tks[i], q=(2 * i, 0), k=(2 * i + 1, 0), v=(2 * i + 1, d))
+             for i in range(len(blocks))]
+    att = ops.attention_group(specs, H, dh, proj)
+    pre1 = ops.linear_group([(att[i], _lin(blk.attention.out_proj), qs[i]) for i, blk in enumerate(blocks)])
+    x = ops.layernorm_group([(pre1[i], blk.norm1.weight, blk.norm1.bias) for i, blk in enumerate(blocks)],
+                            blocks[0].norm1.eps)
+    h = ops.linear_group([(x[i], _lin(blk.ffn[0], relu=True), None) for i, blk in enumerate(blocks)])
+    pre2 = ops.linear_group([(h[i], _lin(blk.ffn[3]), x[i]) for i, blk in enumerate(blocks)])
+    return ops.layernorm_group([(pre2[i], blk.norm2.weight, blk.norm2.bias) for i, blk in enumerate(blocks)],
+                               blocks[0].norm2.eps)
+
+
+def _self_attention(mhas: Sequence[_MHAParams], xs: Sequence[torch.Tensor], B: int, Ts: Sequence[int]
+                    ) -> List[torch.Tensor]:
+    """n independent self-attention MHAs without residual/LN (reference :161-163)."""
+    d, H, dh = mhas[0].embed_dim, mhas[0].num_heads, mhas[0].head_dim
+    qkv = ops.linear_group([(x, m.qkv_spec(), None) for m, x in zip(mhas, xs)])
+    specs = [AttnSpec(B, Ts[i], Ts[i], q=(i, 0), k=(i, d), v=(i, 2 * d)) for i in range(len(mhas))]
+    att = ops.attention_group(specs, H, dh, qkv)
+    return ops.linear_group([(att[i], _lin(m.out_proj), None) for i, m in enumerate(mhas)])
+
+
+# ------------------------------------------------------------------------------------------------
+# a4  EarlyFusion  (reference :9-43)
+# ------------------------------------------------------------------------------------------------
+class EarlyFusion(_FusionBase):
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        d = config.fusion_hidden_size
+        self.fusion_layers = nn.Sequential(
+            nn.Linear(3 * d, 2 * d), nn.ReLU(), nn.Dropout(config.fusion_dropout),
+            nn.Linear(2 * d, d), nn.ReLU(), nn.Dropout(config.fusion_dropout))
+
+    def forward(self, text_features, audio_features, video_features) -> torch.Tensor:
+        _check_dropout(self, self.config.fusion_dropout)
+        x = _as_rows(torch.cat([text_features, audio_features, video_features], dim=-1))
+        h = ops.linear(x, *_wb(self.fusion_layers[0]), relu=True)
+        return ops.linear(h, *_wb(self.fusion_layers[3]), relu=True, out_f32=True)
+
+
+def _wb(layer: nn.Linear):
+    return W(layer.weight), (W(layer.bias) if layer.bias is not None else None)
+
+
+# ------------------------------------------------------------------------------------------------
+# a5  LateFusion  (reference :46-90) — three d->7 heads + a 3-way softmax: kept on torch (N = 7 is
+# below the kernels' 4-column granularity and the arithmetic is ~10 kFLOP/sample)
+# ------------------------------------------------------------------------------------------------
+class LateFusion(_FusionBase):
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        d, n = config.fusion_hidden_size, config.num_emotions
+        self.text_classifier = nn.Linear(d, n)
+        self.audio_classifier = nn.Linear(d, n)
+        self.video_classifier = nn.Linear(d, n)
+        self.fusion_weights = nn.Parameter(torch.ones(3) / 3)
+
+    def forward(self, text_features, audio_features, video_features) -> Dict[str, torch.Tensor]:
+        tl = F.linear(text_features.float(), self.text_classifier.weight, self.text_classifier.bias)
+        al = F.linear(audio_features.float(), self.audio_classifier.weight, self.audio_classifier.bias)
+        vl = F.linear(video_features.float(), self.video_classifier.weight, self.video_classifier.bias)
+        w = F.softmax(self.fusion_weights, dim=0)
+        return {"fused_logits": w[0] * tl + w[1] * al + w[2] * vl, "text_logits": tl,
+                "audio_logits": al, "video_logits": vl, "fusion_weights": w}
+
+
+# ------------------------------------------------------------------------------------------------
+# a1  CrossModalTransformer  (reference :182-211)
+# ------------------------------------------------------------------------------------------------
+class CrossModalTransformer(_FusionBase):
+    def __init__(self, config):
+        super().__init__()
+        d = config.fusion_hidden_size
+        self.dropout_p = config.fusion_dropout
+        self.attention = _MHAParams(d, config.fusion_num_heads)
+        self.norm1 = nn.LayerNorm(d)
+        self.norm2 = nn.LayerNorm(d)
+        self.ffn = nn.Sequential(nn.Linear(d, 4 * d), nn.ReLU(), nn.Dropout(config.fusion_dropout),
+                                 nn.Linear(4 * d, d))
+
+    def forward(self, query: torch.Tensor, key_value: torch.Tensor) -> torch.Tensor:
+        _check_dropout(self, self.dropout_p)
+        B, Tq, d = query.shape
+        Tk = key_value.shape[1]
+        y = _cross_blocks([self], [_as_rows(query)], [_as_rows(key_value)], B, [Tq], [Tk])[0]
+        return ops.to_f32(y).reshape(B, Tq, d)
+
+
+# ------------------------------------------------------------------------------------------------
+# a2  MultimodalTransformer (MulT)  (reference :93-179)
+# ------------------------------------------------------------------------------------------------
+class MultimodalTransformer(_FusionBase):
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        d, H = config.fusion_hidden_size, config.fusion_num_heads
+        self.text_to_audio = CrossModalTransformer(config)
+        self.text_to_video = CrossModalTransformer(config)
+        self.audio_to_text = CrossModalTransformer(config)
+        self.audio_to_video = CrossModalTransformer(config)
+        self.video_to_text = CrossModalTransformer(config)
+        self.video_to_audio = CrossModalTransformer(config)
+        self.text_self_attn = _MHAParams(d, H)
+        self.audio_self_attn = _MHAParams(d, H)
+        self.video_self_attn = _MHAParams(d, H)
+        self.final_fusion = nn.Sequential(nn.Linear(3 * d, d), nn.ReLU(), nn.Dropout(config.fusion_dropout))
+
+    def forward(self, text_features, audio_features, video_features) -> Dict[str, torch.Tensor]:
+        _check_dropout(self, self.config.fusion_dropout)
+        if text_features.dim() == 2:                                            # reference :140-143
+            text_features, audio_features, video_features = (
+                text_features.unsqueeze(1), audio_features.unsqueeze(1), video_features.unsqueeze(1))
+        B, Tt, d = text_features.shape
+        Ta, Tv = audio_features.shape[1], video_features.shape[1]
+        t, a, v = _as_rows(text_features), _as_rows(audio_features), _as_rows(video_features)
+        blocks = [self.text_to_audio, self.text_to_video, self.audio_to_text, self.audio_to_video,
+                  self.video_to_text, self.video_to_audio]
+        t_a, t_v, a_t, a_v, v_t, v_a = _cross_blocks(
+            blocks, [t, t, a, a, v, v], [a, v, t, v, t, a], B, [Tt, Tt, Ta, Ta, Tv, Tv],
+            [Ta, Tv, Tt, Tv, Tt, Ta])                                           # :146-153
+        et, ea, ev = ops.add3(t, t_a, t_v), ops.add3(a, a_t, a_v), ops.add3(v, v_t, v_a)   # :156-158
+        ta, aa, va = _self_attention([self.text_self_attn, self.audio_self_attn, self.video_self_attn],
+                                     [et, ea, ev], B, [Tt, Ta, Tv])             # :161-163
+        pooled = ops.meanpool_cat([ta.view(B, Tt, d), aa.view(B, Ta, d), va.view(B, Tv, d)])  # :166-171
+        fused = ops.linear(pooled, *_wb(self.final_fusion[0]), relu=True, out_f32=True)       # :172
+        pf = ops.to_f32(pooled)
+        return {"fused_features": fused, "text_features": pf[:, :d], "audio_features": pf[:, d:2 * d],
+                "video_features": pf[:, 2 * d:]}
+
+
+# ------------------------------------------------------------------------------------------------
+# a6  GraphFusion  (reference :214-291) — dense 3-node GAT (PyG GATConv semantics, parity unpinned)
+# ------------------------------------------------------------------------------------------------
+class _DenseGAT(nn.Module):
+    """Parameters of one PyG ``GATConv(in, out, heads=4, concat=False)`` (names of PyG >= 2.5:
+    ``lin.weight``, ``att_src``, ``att_dst``, ``bias``; 2.3/2.4 checkpoints' ``lin_src``/``lin_dst``
+    are accepted on load).  Glorot initialisation like PyG."""
+    heads = 4
+
+    def __init__(self, in_channels: int, out_channels: int):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.lin = nn.Linear(in_channels, self.heads * out_channels, bias=False)
+        self.att_src = nn.Parameter(torch.empty(1, self.heads, out_channels))
+        self.att_dst = nn.Parameter(torch.empty(1, self.heads, out_channels))
+        self.bias = nn.Parameter(torch.zeros(out_channels))
+        nn.init.xavier_uniform_(self.lin.weight)
+        nn.init.xavier_uniform_(self.att_src)
+        nn.init.xavier_uniform_(self.att_dst)
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        for old in ("lin_src.weight", "lin_dst.weight"):
+            if prefix + old in state_dict:
+                w = state_dict.pop(prefix + old)
+                state_dict.setdefault(prefix + "lin.weight", w)
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+    def forward(self, x: torch.Tensor, B: int) -> torch.Tensor:
+        """x: bf16 (B*3, in) -> fp32 (B, 3, out), ReLU not included."""
+        Hh, C = self.heads, self.out_channels
+        h = ops.linear(x, W(self.lin.weight), None, out_f32=True).view(B, 3, Hh, C)   # MFMA GEMM
+        # 3x3 additive attention per (sample, head): ~100 FLOP — torch glue
+        s_src = (h * self.att_src).sum(-1)
+        s_dst = (h * self.att_dst).sum(-1)
+        e = F.leaky_relu(s_dst.unsqueeze(2) + s_src.unsqueeze(1), 0.2)                 # (B,i,j,H)
+        ex = torch.exp(e - e.max(dim=2, keepdim=True).values)
+        alpha = ex / (ex.sum(dim=2, keepdim=True) + 1e-16)
+        return torch.einsum("bijh,bjhc->bihc", alpha, h).mean(dim=2) + self.bias
+
+
+class GraphFusion(_FusionBase):
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        d, G, L = config.fusion_hidden_size, config.graph_hidden_size, config.graph_num_layers
+        # The reference builds every layer d -> G but feeds layer >= 2 the G-wide output of the layer
+        # before (models/fusion_layers.py:223-232 vs :280-282), so it only runs when G == d or L == 1
+        # (SURVEY.md fact 4).  Here layer l >= 1 takes G inputs — identical shapes to the reference
+        # whenever the reference can run, and a working stack at the default config (G=256, d=512).
+        self.gcn_layers = nn.ModuleList([_DenseGAT(d if l == 0 else G, G) for l in range(L)])
+        self.node_type_embedding = nn.Embedding(3, d)
+        self.output_projection = nn.Linear(G, d)
+
+    def forward(self, text_features, audio_features, video_features) -> torch.Tensor:
+        B = text_features.shape[0]
+        x = torch.stack([text_features.float(), audio_features.float(), video_features.float()], dim=1)
+        x = x + self.node_type_embedding.weight                                        # :255-264
+        for layer in self.gcn_layers:                                                  # :280-282
+            x = torch.relu(layer(_as_rows(x), B))
+        pooled = x.mean(dim=1)                                                         # :285-286
+        return ops.linear(_as_rows(pooled), *_wb(self.output_projection), out_f32=True)
+
+
+# ------------------------------------------------------------------------------------------------
+# a7  ContrastiveFusion  (reference :294-375)
+# ------------------------------------------------------------------------------------------------
+class ContrastiveFusion(_FusionBase):
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.temperature = config.contrastive_temperature
+        d = config.fusion_hidden_size
+        mk = lambda: nn.Sequential(nn.Linear(d, d), nn.ReLU(), nn.Linear(d, d // 2))
+        self.text_projector, self.audio_projector, self.video_projector = mk(), mk(), mk()
+        self.fusion_layer = nn.Sequential(nn.Linear(3 * d, d), nn.ReLU(), nn.Dropout(config.fusion_dropout))
+
+    def forward(self, text_features, audio_features, video_features,
+                compute_contrastive_loss: bool = False) -> Dict[str, torch.Tensor]:
+        _check_dropout(self, self.config.fusion_dropout)
+        xs = [_as_rows(text_features), _as_rows(audio_features), _as_rows(video_features)]
+        projs = [self.text_projector, self.audio_projector, self.video_projector]
+        h = ops.linear_group([(x, _lin(p[0], relu=True), None) for x, p in zip(xs, projs)])
+        z = ops.linear_group([(hh, _lin(p[2]), None) for hh, p in zip(h, projs)], out_f32=True)
+        tp, ap, vp = (F.normalize(t, dim=-1) for t in z)                               # :338-340
+        losses = {}
+        if compute_contrastive_loss:                                                   # :344-347
+            losses = {"text_audio": self.contrastive_loss(tp, ap),
+                      "text_video": self.contrastive_loss(tp, vp),
+                      "audio_video": self.contrastive_loss(ap, vp)}
+        cat = _as_rows(torch.cat([text_features, audio_features, video_features], dim=-1))
+        fused = ops.linear(cat, *_wb(self.fusion_layer[0]), relu=True, out_f32=True)
+        return {"fused_features": fused, "text_proj": tp, "audio_proj": ap, "video_proj": vp,
+                "contrastive_losses": losses}
+
+    def contrastive_loss(self, z1: torch.Tensor, z2: torch.Tensor) -> torch.Tensor:
+        """Symmetric InfoNCE over the (per-rank) batch, reference :361-375; B x B, fp32."""
+        sim = torch.mm(z1, z2.t()) / self.temperature
+        labels = torch.arange(z1.size(0), device=z1.device)
+        return (F.cross_entropy(sim, labels) + F.cross_entropy(sim.t(), labels)) / 2
+
+
+# ------------------------------------------------------------------------------------------------
+# a8  AdaptiveFusion  (reference :378-452)
+# ------------------------------------------------------------------------------------------------
+class AdaptiveFusion(_FusionBase):
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        d = config.fusion_hidden_size
+        self.attention = _MHAParams(d, config.fusion_num_heads)
+        self.text_transform = nn.Linear(d, d)
+        self.audio_transform = nn.Linear(d, d)
+        self.video_transform = nn.Linear(d, d)
+        self.weight_predictor = nn.Sequential(nn.Linear(3 * d, d), nn.ReLU(), nn.Linear(d, 3), nn.Softmax(dim=-1))
+        self.fusion_layer = nn.Sequential(nn.Linear(d, d), nn.ReLU(), nn.Dropout(config.fusion_dropout))
+
+    def forward(self, text_features, audio_features, video_features) -> Dict[str, torch.Tensor]:
+        _check_dropout(self, self.config.fusion_dropout)
+        B, d = text_features.shape
+        mp = self.attention
+        H, dh = mp.num_heads, mp.head_dim
+        xs = [_as_rows(text_features), _as_rows(audio_features), _as_rows(video_features)]
+        tr = ops.linear_group([(x, _lin(l), None) for x, l in
+                               zip(xs, (self.text_transform, self.audio_transform, self.video_transform))])
+        stacked = torch.stack(tr, dim=1).reshape(B * 3, d)                             # (B,3,d) :427-429
+        qkv = ops.linear(stacked, mp.qkv_spec().w, mp.qkv_spec().b)
+        att = ops.attention_group([AttnSpec(B, 3, 3, q=(0, 0), k=(0, d), v=(0, 2 * d))], H, dh, [qkv])[0]
+        attended = ops.linear(att, *_wb(mp.out_proj), out_f32=True).view(B, 3, d)
+        with torch.no_grad():                      # head-averaged 3x3 weights, returned for inspection
+            q4 = qkv.detach().float().view(B, 3, 3, H, dh)
+            sc = torch.einsum("bihd,bjhd->bhij", q4[:, :, 0], q4[:, :, 1]) / math.sqrt(dh)
+            attn_w = F.softmax(sc, dim=-1).mean(dim=1)
+        cat = _as_rows(torch.cat([text_features, audio_features, video_features], dim=-1))
+        hp = ops.linear(cat, *_wb(self.weight_predictor[0]), relu=True, out_f32=True)
+        aw = F.softmax(F.linear(hp, self.weight_predictor[2].weight, self.weight_predictor[2].bias), dim=-1)
+        weighted = (attended * aw.unsqueeze(-1)).sum(dim=1)                            # :441-443
+        fused = ops.linear(_as_rows(weighted), *_wb(self.fusion_layer[0]), relu=True, out_f32=True)
+        return {"fused_features": fused, "attention_weights": attn_w, "adaptive_weights": aw}
+
+
+# ------------------------------------------------------------------------------------------------
+# a9  HierarchicalFusion  (reference :455-520)
+# ------------------------------------------------------------------------------------------------
+class HierarchicalFusion(_FusionBase):
+    """Five branches + meta MLP.  With (B, d) inputs this is the reference semantics (*hier-ref*).
+    With (B, T, d) inputs — which the reference cannot take — the MulT branch
+    consumes the sequences and the other four branches their mean over T: the build-defined
+    *hier-seq* composition of SURVEY.md section 8(d)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        d = config.fusion_hidden_size
+        self.early_fusion = EarlyFusion(config)
+        self.mult_fusion = MultimodalTransformer(config)
+        self.graph_fusion = GraphFusion(config)
+        self.contrastive_fusion = ContrastiveFusion(config)
+        self.adaptive_fusion = AdaptiveFusion(config)
+        self.meta_fusion = nn.Sequential(nn.Linear(5 * d, 2 * d), nn.ReLU(), nn.Dropout(config.fusion_dropout),
+                                         nn.Linear(2 * d, d))
+
+    def forward(self, text_features, audio_features, video_features,
+                compute_contrastive_loss: bool = False) -> Dict[str, torch.Tensor]:
+        _check_dropout(self, self.config.fusion_dropout)
+        seq = (text_features, audio_features, video_features)
+        if text_features.dim() == 3:
+            d = text_features.shape[-1]
+            pooled = ops.to_f32(ops.meanpool_cat([ops.to_bf16(x.contiguous()) for x in seq]))
+            text_features, audio_features, video_features = pooled[:, :d], pooled[:, d:2 * d], pooled[:, 2 * d:]
+        early = self.early_fusion(text_features, audio_features, video_features)
+        mult = self.mult_fusion(*seq)
+        graph = self.graph_fusion(text_features, audio_features, video_features)
+        con = self.contrastive_fusion(text_features, audio_features, video_features, compute_contrastive_loss)
+        ada = self.adaptive_fusion(text_features, audio_features, video_features)
+        allf = _as_rows(torch.cat([early, mult["fused_features"], graph, con["fused_features"],
+                                   ada["fused_features"]], dim=-1))                    # :503-506
+        h = ops.linear(allf, *_wb(self.meta_fusion[0]), relu=True)
+        final = ops.linear(h, *_wb(self.meta_fusion[3]), out_f32=True)
+        return {"fused_features": final, "early_features": early, "mult_features": mult["fused_features"],
+                "graph_features": graph, "contrastive_features": con["fused_features"],
+                "adaptive_features": ada["fused_features"],
+                "contrastive_losses": con.get("contrastive_losses", {}),
+                "attention_weights": ada.get("attention_weights"),
+                "adaptive_weights": ada.get("adaptive_weights")}

@@ -1,0 +1,229 @@
+"""GPU: each HIP kernel of libmmfusion.so, called through the C ABI (ctypes), against an fp32
+restatement of the same op on the bf16-rounded inputs.  Tolerances are written per test:
+bf16 outputs carry a relative rounding error of 2^-9 per element; gradients that pass through a
+bf16 intermediate are compared relative to the tensor's scale."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from mmfusion import lib, ops  # noqa: E402
+from mmfusion.lib import (EPI_ACCUM, EPI_ADD_AUX, EPI_BIAS, EPI_MASK_AUX, EPI_RELU, GEMM_NN, GEMM_NT,
+                          GEMM_TN)  # noqa: E402
+
+DEV = "cuda"
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale)
+
+
+def bf(x):
+    return x.to(torch.bfloat16).to(DEV)
+
+
+def rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+# ---------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 72, 40), (16, 768, 2304), (480, 1536, 768),
+                                   (1000, 264, 3072), (3, 8, 8)])
+def test_gemm_nt_epilogues(M, N, K):
+    A, B_, bias, aux = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3), rnd(M, N, seed=4)
+    a16, b16, aux16 = bf(A), bf(B_), bf(aux)
+    ref = a16.float().cpu() @ b16.float().cpu().t()
+    # plain, f32 out
+    C = torch.full((M, N), float("nan"), device=DEV)
+    ops.gemm(GEMM_NT, a16, b16, C)
+    assert rel(C, ref) < 1e-5
+    # bias + relu, bf16 out
+    C16 = torch.empty((M, N), dtype=torch.bfloat16, device=DEV)
+    ops.gemm(GEMM_NT, a16, b16, C16, bias=bias.to(DEV), epilogue=EPI_BIAS | EPI_RELU)
+    assert rel(C16, torch.relu(ref + bias)) < 2 ** -8
+    # bias + residual
+    ops.gemm(GEMM_NT, a16, b16, C16, bias=bias.to(DEV), aux=aux16, epilogue=EPI_BIAS | EPI_ADD_AUX)
+    assert rel(C16, ref + bias + aux16.float().cpu()) < 2 ** -8
+    # mask by aux > 0
+    ops.gemm(GEMM_NT, a16, b16, C, aux=aux16, epilogue=EPI_MASK_AUX)
+    assert rel(C, ref * (aux16.float().cpu() > 0)) < 1e-5
+    # accumulate
+    C.fill_(1.0)
+    ops.gemm(GEMM_NT, a16, b16, C, epilogue=EPI_ACCUM)
+    assert rel(C, ref + 1.0) < 1e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 72, 40), (16, 2304, 768), (8192 // 8, 768, 3072),
+                                   (30, 96, 192)])
+def test_gemm_nn_dgrad(M, N, K):
+    A, B_ = rnd(M, K, seed=5), rnd(K, N, seed=6, scale=K ** -0.5)
+    a16, b16 = bf(A), bf(B_)
+    C = torch.full((M, N), float("nan"), device=DEV)
+    ops.gemm(GEMM_NN, a16, b16, C)
+    assert rel(C, a16.float().cpu() @ b16.float().cpu()) < 1e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (72, 200, 100), (768, 768, 1000), (3072, 96, 16),
+                                   (64, 2304, 48), (8, 8, 3)])
+def test_gemm_tn_wgrad(M, N, K):
+    A, B_ = rnd(K, M, seed=7), rnd(K, N, seed=8, scale=K ** -0.5)
+    a16, b16 = bf(A), bf(B_)
+    C = torch.zeros((M, N), device=DEV)
+    ops.gemm(GEMM_TN, a16, b16, C, epilogue=EPI_ACCUM)
+    ops.gemm(GEMM_TN, a16, b16, C, epilogue=EPI_ACCUM)
+    assert rel(C, 2 * (a16.float().cpu().t() @ b16.float().cpu())) < 1e-5
+
+
+def test_gemm_identity_asymmetric():
+    """A = I with an asymmetric B catches a transposed C write (guide section 3)."""
+    n = 128
+    eye = torch.eye(n)
+    Bm = torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 251 - 100.0     # exact in bf16? values <= 151
+    C = torch.empty((n, n), device=DEV)
+    ops.gemm(GEMM_NT, bf(eye), bf(Bm), C)          # C = I B^T = B^T
+    assert torch.equal(C.cpu(), Bm.t().contiguous())
+    ops.gemm(GEMM_NN, bf(eye), bf(Bm), C)          # C = I B = B
+    assert torch.equal(C.cpu(), Bm)
+    ops.gemm(GEMM_TN, bf(eye), bf(Bm), C)          # C = I^T B = B
+    assert torch.equal(C.cpu(), Bm)
+    ops.gemm(GEMM_TN, bf(Bm), bf(eye), C)          # C = B^T I
+    assert torch.equal(C.cpu(), Bm.t().contiguous())
+
+
+def test_gemm_grouped_and_strided():
+    """several problems in one launch, operands that are column slices of wider buffers"""
+    big = bf(rnd(300, 512, seed=9))
+    w1, w2 = bf(rnd(64, 128, seed=10, scale=0.1)), bf(rnd(200, 256, seed=11, scale=0.1))
+    x1, x2 = big[:, 128:256], big[:100, 256:512]
+    out = torch.zeros((300, 512), dtype=torch.bfloat16, device=DEV)
+    y1, y2 = out[:, 0:64], out[:100, 64:264]
+    ops.gemm_group(GEMM_NT, [(x1, w1, y1, None, None), (x2, w2, y2, None, None)], 0)
+    assert rel(y1, x1.float().cpu() @ w1.float().cpu().t()) < 2 ** -8
+    assert rel(y2, x2.float().cpu() @ w2.float().cpu().t()) < 2 ** -8
+    assert float(out[:, 264:].float().abs().max()) == 0.0 and float(out[100:, 64:264].float().abs().max()) == 0.0
+
+
+def test_gemm_rejects_bad_shapes():
+    a, b = bf(rnd(16, 12)), bf(rnd(8, 12))
+    with pytest.raises(RuntimeError, match="granularity"):
+        ops.gemm(GEMM_NT, a, b, torch.empty((16, 8), device=DEV))
+
+
+# ---------------------------------------------------------------------------------------- LayerNorm
+@pytest.mark.parametrize("rows,d", [(7, 64), (1000, 768), (130, 192), (33, 1536), (5, 2048)])
+def test_layernorm_fwd_bwd(rows, d):
+    x, gam, bet, dy = rnd(rows, d, seed=1) * 2 + 0.5, rnd(d, seed=2) * 0.1 + 1, rnd(d, seed=3) * 0.1, rnd(rows, d, seed=4)
+    x16, dy16 = bf(x), bf(dy)
+    g = torch.nn.Parameter(gam.to(DEV))
+    b = torch.nn.Parameter(bet.to(DEV))
+    g.grad, b.grad = torch.zeros_like(g), torch.zeros_like(b)
+    xin = x16.clone().requires_grad_(True)
+    y = ops.layernorm_group([(xin, g, b)])[0]
+    y.backward(dy16)
+    xr = x16.float().cpu().requires_grad_(True)
+    gr, br = gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
+    yr = torch.nn.functional.layer_norm(xr, (d,), gr, br, 1e-5)
+    yr.backward(dy16.float().cpu())
+    assert rel(y, yr.detach()) < 2 ** -7
+    assert rel(xin.grad, xr.grad) < 2 ** -7
+    assert rel(g.grad, gr.grad) < 1e-3
+    assert rel(b.grad, br.grad) < 1e-3
+
+
+# ---------------------------------------------------------------------------------------- attention
+def attn_ref(q, k, v, H):
+    """fp32 reference on (B,T,H*dh) tensors; returns output (B,Tq,d)."""
+    B, Tq, d = q.shape
+    dh = d // H
+    qh = q.view(B, Tq, H, dh).transpose(1, 2)
+    kh = k.view(B, -1, H, dh).transpose(1, 2)
+    vh = v.view(B, -1, H, dh).transpose(1, 2)
+    p = torch.softmax(qh @ kh.transpose(-1, -2) / math.sqrt(dh), dim=-1)
+    return (p @ vh).transpose(1, 2).reshape(B, Tq, d)
+
+
+@pytest.mark.parametrize("B,H,dh,Tq,Tk", [(2, 2, 96, 70, 40), (1, 3, 96, 128, 64), (2, 2, 64, 33, 150),
+                                          (3, 2, 96, 1, 1), (2, 8, 96, 30, 400), (1, 2, 64, 200, 3),
+                                          (1, 1, 96, 257, 129)])
+def test_attention_fwd_bwd(B, H, dh, Tq, Tk):
+    d = H * dh
+    q, kv, do = rnd(B, Tq, d, seed=1), rnd(B, Tk, 2 * d, seed=2), rnd(B, Tq, d, seed=3)
+    q16 = bf(q).reshape(B * Tq, d).requires_grad_(True)
+    kv16 = bf(kv).reshape(B * Tk, 2 * d).requires_grad_(True)
+    o = ops.attention_group([ops.AttnSpec(B, Tq, Tk, q=(0, 0), k=(1, 0), v=(1, d))], H, dh, [q16, kv16])[0]
+    o.backward(bf(do).reshape(B * Tq, d))
+    qr = q16.detach().float().cpu().view(B, Tq, d).requires_grad_(True)
+    kvr = kv16.detach().float().cpu().view(B, Tk, 2 * d).requires_grad_(True)
+    orf = attn_ref(qr, kvr[..., :d], kvr[..., d:], H)
+    orf.backward(bf(do).float().cpu())
+    assert rel(o.view(B, Tq, d), orf.detach()) < 2 ** -7
+    assert rel(q16.grad.view(B, Tq, d), qr.grad) < 2e-2
+    assert rel(kv16.grad.view(B, Tk, 2 * d)[..., :d], kvr.grad[..., :d]) < 2e-2
+    assert rel(kv16.grad.view(B, Tk, 2 * d)[..., d:], kvr.grad[..., d:]) < 2e-2
+
+
+def test_attention_grouped_self_packed():
+    """two problems in one launch; q, k, v as column ranges of one packed (rows, 3d) buffer"""
+    H, dh = 2, 96
+    d = H * dh
+    specs, srcs, refs = [], [], []
+    for i, (B, T) in enumerate([(2, 50), (1, 130)]):
+        qkv = bf(rnd(B * T, 3 * d, seed=20 + i)).requires_grad_(True)
+        srcs.append(qkv)
+        specs.append(ops.AttnSpec(B, T, T, q=(i, 0), k=(i, d), v=(i, 2 * d)))
+    outs = ops.attention_group(specs, H, dh, srcs)
+    (outs[0].float().sum() + 2 * outs[1].float().sum()).backward()
+    for i, (B, T) in enumerate([(2, 50), (1, 130)]):
+        r = srcs[i].detach().float().cpu().view(B, T, 3 * d).requires_grad_(True)
+        o = attn_ref(r[..., :d], r[..., d:2 * d], r[..., 2 * d:], H)
+        (o.sum() * (i + 1)).backward()
+        assert rel(outs[i].view(B, T, d), o.detach()) < 2 ** -7
+        assert rel(srcs[i].grad.view(B, T, 3 * d), r.grad) < 2e-2
+
+
+def test_attention_online_softmax_rescale_branch():
+    """Force the running max to jump at a later KV tile (guide rule 26): one key far above the rest."""
+    B, H, dh, Tq, Tk = 1, 1, 96, 32, 200
+    q, k, v = rnd(B, Tq, dh, seed=1), rnd(B, Tk, dh, seed=2), rnd(B, Tk, dh, seed=3)
+    k[0, 170] = q[0, 5] * 4.0                       # spikes the score of query 5 in the third tile
+    q16 = bf(q).reshape(Tq, dh)
+    kv16 = bf(torch.cat([k, v], -1)).reshape(Tk, 2 * dh)
+    o = ops.attention_group([ops.AttnSpec(B, Tq, Tk, q=(0, 0), k=(1, 0), v=(1, dh))], H, dh, [q16, kv16])[0]
+    ref = attn_ref(q16.float().cpu().view(1, Tq, dh), kv16.float().cpu()[:, :dh].reshape(1, Tk, dh),
+                   kv16.float().cpu()[:, dh:].reshape(1, Tk, dh), 1)
+    assert rel(o.view(1, Tq, dh), ref) < 2 ** -7
+
+
+# ---------------------------------------------------------------------------------------- streaming
+def test_cast_add_pool_colsum_relu():
+    x = rnd(1000, 771, seed=1)
+    xg = x.to(DEV)
+    y = ops.cast_to_bf16(xg)
+    assert torch.equal(y.cpu(), x.to(torch.bfloat16))
+    assert torch.equal(ops.cast_to_f32(y).cpu(), x.to(torch.bfloat16).float())
+    a, b, c = bf(rnd(3, 50, 64, seed=2)), bf(rnd(3, 50, 64, seed=3)), bf(rnd(3, 50, 64, seed=4))
+    s = ops.add3(a, b, c)
+    assert rel(s, a.float() + b.float() + c.float()) < 2 ** -8
+    assert rel(ops.add3(a, b), a.float() + b.float()) < 2 ** -8
+    xs = [bf(rnd(4, T, 192, seed=10 + T)).requires_grad_(True) for T in (70, 40, 6)]
+    p = ops.meanpool_cat(xs)
+    ref = torch.cat([t.float().mean(1) for t in xs], -1)
+    assert rel(p, ref) < 2 ** -8
+    g = bf(rnd(4, 3 * 192, seed=5))
+    p.backward(g)
+    for i, t in enumerate(xs):
+        exp = (g.float()[:, i * 192:(i + 1) * 192] / t.shape[1]).unsqueeze(1).expand_as(t)
+        assert rel(t.grad, exp) < 2 ** -8
+    m = bf(rnd(777, 264, seed=6))
+    out = torch.ones(264, device=DEV)
+    L = lib.load()
+    lib.check(L.mmf_colsum_bf16(m.data_ptr(), out.data_ptr(), 777, 264, 264, lib.stream_ptr()))
+    assert rel(out, m.float().sum(0) + 1) < 1e-4
+    dy, yv = bf(rnd(999, seed=7)), bf(rnd(999, seed=8))
+    dx = torch.empty_like(dy)
+    lib.check(L.mmf_relu_bwd_bf16(dy.data_ptr(), yv.data_ptr(), dx.data_ptr(), 999, lib.stream_ptr()))
+    assert torch.equal(dx, torch.where(yv.float() > 0, dy, torch.zeros_like(dy)))
