@@ -1,0 +1,270 @@
+#!/usr/bin/env python3
+"""bench.py — fusion fwd+bwd samples/s (BASELINE.json metric) on N MI355X of one node.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload mult|hier] [--no-graph]
+                    [--no-cpu-baseline]
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[1]): MulT cross-modal attention,
+bf16 storage / f32 accumulate, synthetic features text (16,512,768), audio (16,400,768),
+video (16,30,768) ~ N(0,1) from seed 1234+rank, default-initialised weights from
+torch.manual_seed(0), fusion_dropout = 0, loss = fused_features.sum().
+
+One "step" = fp32->bf16 weight-shadow cast, gradient-arena zeroing, forward, backward — and, for
+N > 1, the RCCL all-reduce (mean) of the flat gradient arena, the path's one exchange step.
+Inputs are resident in HBM before the timed region.  Steps are replayed from one captured
+hipGraph unless --no-graph.  Rank 0 prints ONE JSON line.
+
+roofline: HIP-event durations of every grouped GEMM / attention launch are collected in a
+separate eager pass after the timed region (same process, same shapes); the dominant kernel is
+the label with the largest total time; achieved = its algorithmic FLOPs / its time.
+cpu_baseline: oracle/ref_cpu.py (fp32, all host cores) timed on rank 0 at N = 1 on the same
+workload: 1 warm-up + best of 2 steps.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+for p in (REPO, os.path.join(REPO, "simple-multimodal_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+os.environ.setdefault("MMFUSION_CONFIG_MKDIRS", "0")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+
+BF16_MFMA_PEAK_TFLOPS = 2500.0      # dense, MI355X_MICROARCH.md chip table
+HBM_PEAK_GBS = 8000.0
+
+
+def mult_flops_per_sample(Tt, Ta, Tv, d):
+    """Algorithmic forward FLOPs of MulT per sample: 6 cross blocks
+    20 Tq d^2 + 4 Tk d^2 + 4 Tq Tk d, 3 self blocks 8 T d^2 + 4 T^2 d, final 6 d^2."""
+    pairs = [(Tt, Ta), (Tt, Tv), (Ta, Tt), (Ta, Tv), (Tv, Tt), (Tv, Ta)]
+    cross = sum(20 * q * d * d + 4 * k * d * d + 4 * q * k * d for q, k in pairs)
+    selfa = sum(8 * t * d * d + 4 * t * t * d for t in (Tt, Ta, Tv))
+    return cross + selfa + 6 * d * d
+
+
+def build(workload, device, rank):
+    import config as cfgmod
+    from mmfusion import synth
+    from models import fusion_layers as fl
+    S = synth.C2_SHAPES
+    cfg = cfgmod.ModelConfig()
+    cfg.fusion_hidden_size, cfg.fusion_num_heads, cfg.fusion_dropout = S["d"], S["heads"], 0.0
+    cfg.graph_hidden_size, cfg.graph_num_layers, cfg.graph_dropout = S["d"], 3, 0.0
+    torch.manual_seed(synth.WEIGHT_SEED)
+    model = (fl.MultimodalTransformer if workload == "mult" else fl.HierarchicalFusion)(cfg)
+    model = model.to(device).train()
+    xs = [t.to(device) for t in synth.make_features(S["B"], (S["T_text"], S["T_audio"], S["T_frames"]), S["d"],
+                                                    seed=synth.INPUT_SEED + rank)]
+    return cfg, model, xs
+
+
+def make_step(workload, model, xs, arena):
+    def step():
+        # the module's own entry hook re-casts the fp32 masters to the bf16 shadow on every training
+        # forward (what autocast does per forward), so the cast is inside the timed step
+        arena.zero_grad()
+        if workload == "mult":
+            out = model(*xs)
+            loss = out["fused_features"].sum()
+        else:
+            out = model(*xs, compute_contrastive_loss=True)
+            loss = out["fused_features"].sum() + 0.1 * sum(out["contrastive_losses"].values())
+        loss.backward()
+        return loss
+    return step
+
+
+def host_cores():
+    """CPU threads this process may really use: affinity mask, cgroup quota, and the GPU box's
+    documented per-GPU share (16) — os.cpu_count() reports the whole 256-thread host."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+            if quota != "max":
+                n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, int(os.environ.get("MMF_CPU_BASELINE_THREADS", "16"))))
+
+
+def cpu_baseline(workload):
+    """oracle (fp32 CPU restatement) on the same workload; returns dict for the JSON line."""
+    from mmfusion import synth
+    from oracle import ref_cpu
+    import config as cfgmod
+    from models import fusion_layers as fl
+    S = synth.C2_SHAPES
+    cfg = cfgmod.ModelConfig()
+    cfg.fusion_hidden_size, cfg.fusion_num_heads, cfg.fusion_dropout = S["d"], S["heads"], 0.0
+    torch.manual_seed(synth.WEIGHT_SEED)
+    m = fl.MultimodalTransformer(cfg)                          # parameter container only (CPU, never called)
+    P = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    xs = synth.make_features(S["B"], (S["T_text"], S["T_audio"], S["T_frames"]), S["d"])
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    best = float("inf")
+    for i in range(3):
+        for p in P.values():
+            p.grad = None
+        t0 = time.perf_counter()
+        out = ref_cpu.multimodal_transformer(P, "", *xs, S["heads"])
+        out["fused_features"].sum().backward()
+        dt = time.perf_counter() - t0
+        if i > 0:
+            best = min(best, dt)
+    model_name = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model_name = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"value": round(S["B"] / best, 3), "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/ref_cpu.py MulT fwd+bwd fp32, B=16 T=512/400/30 d=768, 1 warm-up + best of 2 "
+                      f"steps ({best:.2f} s/step) on {model_name}"}
+
+
+def kernel_profile(step, nsteps):
+    """Eager pass with HIP events around every grouped GEMM / attention launch."""
+    from mmfusion import lib
+    lib.PROFILE = []
+    for _ in range(nsteps):
+        step()
+    torch.cuda.synchronize()
+    agg = {}
+    for label, flops, e0, e1 in lib.PROFILE:
+        a = agg.setdefault(label, [0.0, 0.0, 0])
+        a[0] += e0.elapsed_time(e1)
+        a[1] += flops
+        a[2] += 1
+    lib.PROFILE = None
+    return {k: {"ms_total": v[0], "flops_total": v[1], "launches": v[2]} for k, v in agg.items()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", choices=["mult", "hier"], default="mult")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-steps", type=int, default=5)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from mmfusion import arena as arena_mod, synth
+    cfg, model, xs = build(args.workload, device, rank)
+    arena = arena_mod.ensure(model)
+    eager_step = make_step(args.workload, model, xs, arena)
+
+    use_graph = not args.no_graph
+    graph = None
+    if use_graph:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                eager_step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            eager_step()
+
+    def run_step():
+        if graph is not None:
+            graph.replay()
+        else:
+            eager_step()
+        if world > 1:
+            dist.all_reduce(arena.grads, op=dist.ReduceOp.SUM)
+            arena.grads.mul_(1.0 / world)
+
+    for _ in range(args.warmup):
+        run_step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    S = synth.C2_SHAPES
+    B = S["B"]
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * B * args.steps / elapsed
+
+    if rank == 0:
+        prof = kernel_profile(eager_step, args.profile_steps)
+        dom = max(prof, key=lambda k: prof[k]["ms_total"])
+        dsec = prof[dom]["ms_total"] * 1e-3
+        ach = prof[dom]["flops_total"] / dsec / 1e12
+        roofline = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": BF16_MFMA_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "avg_launch_us": round(prof[dom]["ms_total"] * 1e3 / prof[dom]["launches"], 2),
+                    "launches_per_step": prof[dom]["launches"] // args.profile_steps}
+        kernels = {k: {"us_per_step": round(v["ms_total"] * 1e3 / args.profile_steps, 1),
+                       "tflops": round(v["flops_total"] / (v["ms_total"] * 1e-3) / 1e12, 1) if v["ms_total"] > 0 else None,
+                       "launches_per_step": v["launches"] // args.profile_steps} for k, v in sorted(prof.items())}
+        fwd_flops = mult_flops_per_sample(S["T_text"], S["T_audio"], S["T_frames"], S["d"])
+        line = {
+            "metric": "fusion fwd+bwd samples/sec at B=16 d=768", "value": round(value, 2), "unit": "samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+            "data": "synthetic",
+            "config": {"workload": f"{'MulT' if args.workload == 'mult' else 'hier-seq'} fwd+bwd, B=16/GPU, "
+                                   f"T_text=512 T_audio=400 T_frames=30 d=768 H=8, fusion_dropout=0",
+                       "global_batch": B * world, "parallelism": f"dp{world}",
+                       "graph_replay": bool(use_graph)},
+            "step_tflops": round(3 * fwd_flops * B / (ms_per_step * 1e-3) / 1e12, 1) if args.workload == "mult" else None,
+            "roofline": roofline,
+            "kernels": kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.workload)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

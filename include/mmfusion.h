@@ -68,14 +68,18 @@ enum {
   MMF_EPI_RELU = 2,
   MMF_EPI_MASK_AUX = 4,
   MMF_EPI_ADD_AUX = 8,
-  MMF_EPI_ACCUM = 16
+  MMF_EPI_ACCUM = 16,
+  /* TN only: additionally `bias[m] += sum_k A[k][m]` (f32 atomics) — the nn.Linear bias gradient
+   * (column sums of dy) taken from the A tiles the wgrad kernel stages anyway; `bias` is then an
+   * OUTPUT of length M and MMF_EPI_BIAS must not be set. */
+  MMF_EPI_COLSUM_A = 32
 };
 
 typedef struct mmf_gemm_problem {
   const void* A;      /* bf16 */
   const void* B;      /* bf16 */
   void* C;            /* bf16 or f32 */
-  const float* bias;  /* f32 [N] or NULL */
+  const float* bias;  /* f32 [N] or NULL (MMF_EPI_COLSUM_A: f32 [M], accumulated into) */
   const void* aux;    /* bf16 [M][ldaux] or NULL */
   int32_t M, N, K;
   int32_t lda, ldb, ldc, ldaux;
@@ -116,7 +120,8 @@ int mmf_attn_bwd_grouped(const mmf_attn_problem* problems, int num_problems, int
  * wavefront per row, f32 statistics by wave reduction.  Replaces nn.LayerNorm at
  * models/fusion_layers.py:205,209 (the residual add is fused into the producing GEMM's epilogue).
  * Forward saves mean and rstd (f32 [rows]).  Backward writes dx (bf16) and ADDS the
- * per-column sums into dgamma/dbeta (f32 [d], caller zeroes or accumulates).
+ * per-column sums into dgamma/dbeta (f32 [d], caller zeroes or accumulates; problems of one call
+ * must not share dgamma/dbeta).
  * ------------------------------------------------------------------------------------------ */
 #define MMF_LN_MAX_PROBLEMS 8
 typedef struct mmf_ln_problem {
@@ -128,15 +133,18 @@ typedef struct mmf_ln_problem {
   float* rstd;
   const void* dy;       /* bwd: bf16 [rows][d] */
   void* dx;             /* bwd: bf16 [rows][d] */
-  float* dgamma;        /* bwd: f32 [d], accumulated with atomics */
+  float* dgamma;        /* bwd: f32 [d], accumulated into (dgamma += column sums) */
   float* dbeta;
   int32_t rows;
 } mmf_ln_problem;
 
 int mmf_layernorm_fwd_grouped(const mmf_ln_problem* problems, int num_problems, int d, float eps,
                               void* stream);
+/* backward needs an f32 workspace of mmf_layernorm_bwd_workspace_bytes(d) bytes (per-workgroup
+ * column partial sums; a second small kernel adds them into dgamma/dbeta — no same-address atomics). */
+size_t mmf_layernorm_bwd_workspace_bytes(int d);
 int mmf_layernorm_bwd_grouped(const mmf_ln_problem* problems, int num_problems, int d,
-                              void* stream);
+                              void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Streaming helpers (HBM-bound, 16-byte vector accesses)
@@ -151,8 +159,16 @@ int mmf_add3_bf16(const void* a, const void* b, const void* c, void* y, int64_t 
 int mmf_meanpool_fwd(const void* x, void* y, int B, int T, int d, int ldy, void* stream);
 /* dx[b][t][j] = dy[b][j] / T ; dy bf16 with row stride lddy */
 int mmf_meanpool_bwd(const void* dy, void* dx, int B, int T, int d, int lddy, void* stream);
-/* out[n] (+)= sum_m x[m][n]; x bf16 [M][ldx]; out f32, atomically accumulated (bias gradients) */
+/* out[n] (+)= sum_m x[m][n]; x bf16 [M][ldx]; out f32, atomically accumulated (bias gradients:
+ * the column sums of dy for nn.Linear biases).  The grouped form covers several matrices in one launch. */
 int mmf_colsum_bf16(const void* x, float* out, int M, int N, int ldx, void* stream);
+#define MMF_COLSUM_MAX_PROBLEMS 24
+typedef struct mmf_colsum_problem {
+  const void* x;      /* bf16 [M][ldx] */
+  float* out;         /* f32 [N], accumulated */
+  int32_t M, N, ldx;
+} mmf_colsum_problem;
+int mmf_colsum_grouped(const mmf_colsum_problem* problems, int num_problems, void* stream);
 /* relu backward on bf16: dx = dy * (y > 0) */
 int mmf_relu_bwd_bf16(const void* dy, const void* y, void* dx, int64_t n, void* stream);
 

@@ -85,9 +85,28 @@ void add3_kernel(const unsigned short* __restrict__ a, const unsigned short* __r
 __global__ __launch_bounds__(EW_THREADS)
 void relu_bwd_kernel(const unsigned short* __restrict__ dy, const unsigned short* __restrict__ y,
                      unsigned short* __restrict__ dx, int64_t n) {
+  // sign/zero test on the bf16 pattern: y > 0  <=>  not negative and not +-0
+  auto keep = [](unsigned yy) -> unsigned {
+    const unsigned lo = yy & 0xffffu, hi = yy >> 16;
+    return ((!(lo & 0x8000u) && (lo & 0x7fffu)) ? 0x0000ffffu : 0u) |
+           ((!(hi & 0x8000u) && (hi & 0x7fffu)) ? 0xffff0000u : 0u);
+  };
+  const int64_t nvec = n >> 3;
   const int64_t stride = (int64_t)gridDim.x * EW_THREADS;
-  for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n; i += stride) {
-    // sign/zero test on the bf16 pattern: y > 0  <=>  not negative and not +-0
+  const bool aligned = ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(y) |
+                         reinterpret_cast<uintptr_t>(dx)) & 15u) == 0;
+  if (aligned) {
+    for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < nvec; i += stride) {
+      const u32x4_t g = *reinterpret_cast<const u32x4_t*>(dy + i * 8);
+      const u32x4_t v = *reinterpret_cast<const u32x4_t*>(y + i * 8);
+      u32x4_t o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = g[e] & keep(v[e]);
+      *reinterpret_cast<u32x4_t*>(dx + i * 8) = o;
+    }
+  }
+  const int64_t start = aligned ? (nvec << 3) : 0;
+  for (int64_t i = start + (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n; i += stride) {
     const unsigned short yy = y[i];
     dx[i] = (!(yy & 0x8000u) && (yy & 0x7fffu)) ? dy[i] : (unsigned short)0;
   }
@@ -141,19 +160,33 @@ void meanpool_bwd_kernel(const unsigned short* __restrict__ dy, unsigned short* 
   }
 }
 
-// column sums: grid (ceil(N/512), row blocks); 4 waves split the block's rows; one atomic per column.
-constexpr int COLSUM_ROWS = 256;
+// column sums (bias gradients), grouped: one launch covers several (x, out) problems.  A workgroup
+// owns 64 rows x 512 columns: lane -> 8 columns, the 4 waves split the rows, LDS combine, one f32
+// atomic per column per workgroup (M/64 adders per address, spread over the whole launch).
+constexpr int COLSUM_ROWS = 64;
+struct ColsumArgs {
+  int nprob;
+  int blk_start[MMF_COLSUM_MAX_PROBLEMS + 1];
+  mmf_colsum_problem p[MMF_COLSUM_MAX_PROBLEMS];
+};
+
 __global__ __launch_bounds__(256)
-void colsum_kernel(const unsigned short* __restrict__ x, float* __restrict__ out, int M, int N, int ldx) {
+void colsum_kernel(const ColsumArgs a) {
   __shared__ float red[3][512];
+  int pi = 0;
+  while (pi + 1 < a.nprob && (int)blockIdx.x >= a.blk_start[pi + 1]) ++pi;
+  const mmf_colsum_problem& P = a.p[pi];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int col = (blockIdx.x * 64 + lane) * 8;
-  const int r0 = blockIdx.y * COLSUM_ROWS;
-  const int r1 = min(M, r0 + COLSUM_ROWS);
+  const int ncc = (P.N + 511) / 512;
+  const int t = (int)blockIdx.x - a.blk_start[pi];
+  const int col = ((t % ncc) * 64 + lane) * 8;
+  const int r0 = (t / ncc) * COLSUM_ROWS;
+  const int r1 = min(P.M, r0 + COLSUM_ROWS);
+  const unsigned short* __restrict__ x = static_cast<const unsigned short*>(P.x);
   float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  if (col < N) {
+  if (col < P.N) {
     for (int r = r0 + wave; r < r1; r += 4) {
-      const u32x4_t w = *reinterpret_cast<const u32x4_t*>(x + (size_t)r * ldx + col);
+      const u32x4_t w = *reinterpret_cast<const u32x4_t*>(x + (size_t)r * P.ldx + col);
       s[0] += bf16lo(w[0]); s[1] += bf16hi(w[0]); s[2] += bf16lo(w[1]); s[3] += bf16hi(w[1]);
       s[4] += bf16lo(w[2]); s[5] += bf16hi(w[2]); s[6] += bf16lo(w[3]); s[7] += bf16hi(w[3]);
     }
@@ -163,10 +196,10 @@ void colsum_kernel(const unsigned short* __restrict__ x, float* __restrict__ out
     for (int e = 0; e < 8; ++e) red[wave - 1][lane * 8 + e] = s[e];
   }
   __syncthreads();
-  if (wave == 0 && col < N) {
+  if (wave == 0 && col < P.N) {
 #pragma unroll
     for (int e = 0; e < 8; ++e)
-      atomicAdd(out + col + e, s[e] + red[0][lane * 8 + e] + red[1][lane * 8 + e] + red[2][lane * 8 + e]);
+      atomicAdd(P.out + col + e, s[e] + red[0][lane * 8 + e] + red[1][lane * 8 + e] + red[2][lane * 8 + e]);
   }
 }
 
@@ -234,12 +267,28 @@ extern "C" int mmf_meanpool_bwd(const void* dy, void* dx, int B, int T, int d, i
   return MMF_OK;
 }
 
-extern "C" int mmf_colsum_bf16(const void* x, float* out, int M, int N, int ldx, void* stream) {
-  if (M <= 0 || N <= 0 || (N & 7) || (ldx & 7) || ldx < N)
-    MMF_FAIL(MMF_E_SHAPE, "mmf_colsum_bf16: M=%d N=%d ldx=%d (N, ldx multiples of 8)", M, N, ldx);
-  EW_PTR_CHECK("mmf_colsum_bf16", x && out && mmf_aligned16(x));
-  hipLaunchKernelGGL(colsum_kernel, dim3((N + 511) / 512, (M + COLSUM_ROWS - 1) / COLSUM_ROWS), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), static_cast<const unsigned short*>(x), out, M, N, ldx);
-  MMF_CHECK_LAUNCH("mmf_colsum_bf16");
+extern "C" int mmf_colsum_grouped(const mmf_colsum_problem* problems, int num_problems, void* stream) {
+  if (!problems || num_problems <= 0 || num_problems > MMF_COLSUM_MAX_PROBLEMS)
+    MMF_FAIL(MMF_E_SHAPE, "mmf_colsum_grouped: num_problems=%d out of range", num_problems);
+  ColsumArgs a; a.nprob = num_problems;
+  int total = 0;
+  for (int i = 0; i < num_problems; ++i) {
+    const mmf_colsum_problem& p = problems[i];
+    if (p.M <= 0 || p.N <= 0 || (p.N & 7) || (p.ldx & 7) || p.ldx < p.N)
+      MMF_FAIL(MMF_E_SHAPE, "mmf_colsum_grouped[%d]: M=%d N=%d ldx=%d (N, ldx multiples of 8)", i, p.M, p.N, p.ldx);
+    if (!p.x || !p.out || !mmf_aligned16(p.x)) MMF_FAIL(MMF_E_ALIGN, "mmf_colsum_grouped[%d]: null or unaligned pointer", i);
+    a.blk_start[i] = total;
+    total += ((p.N + 511) / 512) * ((p.M + COLSUM_ROWS - 1) / COLSUM_ROWS);
+    a.p[i] = p;
+  }
+  a.blk_start[num_problems] = total;
+  hipLaunchKernelGGL(colsum_kernel, dim3(total), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  MMF_CHECK_LAUNCH("mmf_colsum_grouped");
   return MMF_OK;
+}
+
+extern "C" int mmf_colsum_bf16(const void* x, float* out, int M, int N, int ldx, void* stream) {
+  mmf_colsum_problem p;
+  p.x = x; p.out = out; p.M = M; p.N = N; p.ldx = ldx;
+  return mmf_colsum_grouped(&p, 1, stream);
 }

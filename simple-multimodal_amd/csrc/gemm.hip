@@ -123,9 +123,24 @@ void gemm_grouped_kernel(const GemmArgs args) {
   u32x4_t ra[4], rb[4];
   const int nk = (K + BK - 1) / BK;
 
+  // wgrad only: bias gradient = column sums of dy = sums over k of the A operand.  The n-tile-0
+  // workgroup of every m-tile adds up the A chunks it stages anyway (a thread always stages the
+  // same 8 columns: chunk id = tid + 256 i keeps (id & 15)), so db costs no extra HBM traffic.
+  const bool do_colsum = A_KR && (args.epi & MMF_EPI_COLSUM_A) && n0 == 0;
+  float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  auto colsum_acc = [&]() {
+    if (A_KR && do_colsum) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { cs[2 * e] += bf16lo(ra[i][e]); cs[2 * e + 1] += bf16hi(ra[i][e]); }
+    }
+  };
+
   stage_load<A_KR>(ra, Ag, P.lda, m0, M, 0, K, tid);
   stage_load<B_KR>(rb, Bg, P.ldb, n0, N, 0, K, tid);
-  stage_store<A_KR>(ra, smem, tid);
+  colsum_acc();                                   // (adds where the registers are consumed anyway,
+  stage_store<A_KR>(ra, smem, tid);               //  never right behind the loads: that would stall)
   stage_store<B_KR>(rb, smem + TILE_BYTES, tid);
   __syncthreads();
 
@@ -153,11 +168,25 @@ void gemm_grouped_kernel(const GemmArgs args) {
     }
     if (more) {                                   // other buffer: its last readers passed the
       char* dA = smem + (cur ^ 1) * 2 * TILE_BYTES;   // barrier that ended the previous k-step
+      colsum_acc();
       stage_store<A_KR>(ra, dA, tid);
       stage_store<B_KR>(rb, dA + TILE_BYTES, tid);
     }
     __syncthreads();
     cur ^= 1;
+  }
+
+  if (A_KR && do_colsum) {           // 16 row-groups (tid >> 4) x 16 column chunks (tid & 15) -> 128 sums
+    float* red = reinterpret_cast<float*>(smem);           // main loop ended on a barrier: LDS is free
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[(tid >> 4) * 128 + (tid & 15) * 8 + e] = cs[e];
+    __syncthreads();
+    if (tid < 128 && m0 + tid < M) {
+      float t = 0.f;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) t += red[g * 128 + tid];
+      atomicAdd(const_cast<float*>(P.bias) + m0 + tid, t);
+    }
   }
 
   // ---- epilogue: lane owns C[m][n..n+3] for each of its 16 MFMA tiles ------------------------------
@@ -222,6 +251,8 @@ extern "C" int mmf_gemm_grouped(const mmf_gemm_problem* problems, int num_proble
     MMF_FAIL(MMF_E_UNSUPPORTED, "mmf_gemm_grouped: MMF_EPI_ACCUM needs f32 output");
   if ((epilogue & MMF_EPI_MASK_AUX) && (epilogue & MMF_EPI_ADD_AUX))
     MMF_FAIL(MMF_E_UNSUPPORTED, "mmf_gemm_grouped: MASK_AUX and ADD_AUX are exclusive");
+  if ((epilogue & MMF_EPI_COLSUM_A) && (layout != MMF_GEMM_TN || (epilogue & MMF_EPI_BIAS)))
+    MMF_FAIL(MMF_E_UNSUPPORTED, "mmf_gemm_grouped: COLSUM_A is a TN (wgrad) epilogue and excludes BIAS");
   GemmArgs a;
   a.nprob = num_problems;
   a.epi = epilogue;
@@ -231,7 +262,7 @@ extern "C" int mmf_gemm_grouped(const mmf_gemm_problem* problems, int num_proble
     if (p.M <= 0 || p.N <= 0 || p.K <= 0)
       MMF_FAIL(MMF_E_SHAPE, "mmf_gemm_grouped[%d]: empty problem M=%d N=%d K=%d", i, p.M, p.N, p.K);
     if (!p.A || !p.B || !p.C) MMF_FAIL(MMF_E_SHAPE, "mmf_gemm_grouped[%d]: null operand", i);
-    if ((epilogue & MMF_EPI_BIAS) && !p.bias) MMF_FAIL(MMF_E_SHAPE, "mmf_gemm_grouped[%d]: bias is null", i);
+    if ((epilogue & (MMF_EPI_BIAS | MMF_EPI_COLSUM_A)) && !p.bias) MMF_FAIL(MMF_E_SHAPE, "mmf_gemm_grouped[%d]: bias is null", i);
     if ((epilogue & (MMF_EPI_MASK_AUX | MMF_EPI_ADD_AUX)) && !p.aux)
       MMF_FAIL(MMF_E_SHAPE, "mmf_gemm_grouped[%d]: aux is null", i);
     // the contiguous extent of each operand must be a multiple of 8 elements (16-B vector loads)

@@ -9,10 +9,13 @@ namespace {
 constexpr int ROWS_PER_BLOCK = 4;      // 4 waves, one row each
 constexpr int MAX_CH = 4;              // 4 chunks x 64 lanes x 8 elements = 2048 columns
 
+constexpr int BWD_BLOCK_BUDGET = 512;   // ~2 workgroups per CU for the whole grouped backward launch
+
 struct LnArgs {
   int nprob;
   int d;
   float eps;
+  float* ws;                             // backward: [total blocks][2][d] partial column sums
   int blk_start[MMF_LN_MAX_PROBLEMS + 1];
   mmf_ln_problem p[MMF_LN_MAX_PROBLEMS];
 };
@@ -157,22 +160,43 @@ void ln_bwd_kernel(const LnArgs a) {
       }
   }
   __syncthreads();
-  if (wave == 0) {
+  if (wave == 0) {                                 // this workgroup's partials -> workspace row
+    float* wsg = a.ws + (size_t)blockIdx.x * 2 * d;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const int col = (c * 64 + lane) * 8;
       if (col < d) {
+        f32x4_t g0, g1, b0, b1;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           float sg = dg[c][e], sb = db[c][e];
 #pragma unroll
           for (int w = 0; w < 3; ++w) { sg += red[0][w][col + e]; sb += red[1][w][col + e]; }
-          atomicAdd(P.dgamma + col + e, sg);
-          atomicAdd(P.dbeta + col + e, sb);
+          if (e < 4) { g0[e] = sg; b0[e] = sb; } else { g1[e - 4] = sg; b1[e - 4] = sb; }
         }
+        *reinterpret_cast<f32x4_t*>(wsg + col) = g0;
+        *reinterpret_cast<f32x4_t*>(wsg + col + 4) = g1;
+        *reinterpret_cast<f32x4_t*>(wsg + d + col) = b0;
+        *reinterpret_cast<f32x4_t*>(wsg + d + col + 4) = b1;
       }
     }
   }
+}
+
+// second phase: dgamma[j] += sum over the problem's workgroups of their partials (thread = column)
+__global__ __launch_bounds__(256)
+void ln_bwd_finalize_kernel(const LnArgs a) {
+  const int pi = blockIdx.y;
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= a.d) return;
+  float sg = 0.f, sb = 0.f;
+  for (int b = a.blk_start[pi]; b < a.blk_start[pi + 1]; ++b) {
+    const float* w = a.ws + (size_t)b * 2 * a.d;
+    sg += w[col];
+    sb += w[a.d + col];
+  }
+  a.p[pi].dgamma[col] += sg;
+  a.p[pi].dbeta[col] += sb;
 }
 
 int check_common(const char* who, const mmf_ln_problem* p, int n, int d) {
@@ -186,7 +210,7 @@ int check_common(const char* who, const mmf_ln_problem* p, int n, int d) {
 extern "C" int mmf_layernorm_fwd_grouped(const mmf_ln_problem* problems, int num_problems, int d,
                                          float eps, void* stream) {
   if (int rc = check_common("mmf_layernorm_fwd_grouped", problems, num_problems, d)) return rc;
-  LnArgs a; a.nprob = num_problems; a.d = d; a.eps = eps;
+  LnArgs a; a.nprob = num_problems; a.d = d; a.eps = eps; a.ws = nullptr;
   int total = 0;
   for (int i = 0; i < num_problems; ++i) {
     const mmf_ln_problem& p = problems[i];
@@ -211,22 +235,40 @@ extern "C" int mmf_layernorm_fwd_grouped(const mmf_ln_problem* problems, int num
   return MMF_OK;
 }
 
+extern "C" size_t mmf_layernorm_bwd_workspace_bytes(int d) {
+  return (size_t)(BWD_BLOCK_BUDGET + MMF_LN_MAX_PROBLEMS) * 2 * (size_t)(d > 0 ? d : 0) * sizeof(float);
+}
+
 extern "C" int mmf_layernorm_bwd_grouped(const mmf_ln_problem* problems, int num_problems, int d,
-                                         void* stream) {
+                                         void* workspace, size_t workspace_bytes, void* stream) {
   if (int rc = check_common("mmf_layernorm_bwd_grouped", problems, num_problems, d)) return rc;
-  LnArgs a; a.nprob = num_problems; a.d = d; a.eps = 0.f;
+  if (!workspace || workspace_bytes < mmf_layernorm_bwd_workspace_bytes(d) || !mmf_aligned16(workspace))
+    MMF_FAIL(MMF_E_SHAPE, "mmf_layernorm_bwd_grouped: workspace of %zu bytes (16-byte aligned) required",
+             mmf_layernorm_bwd_workspace_bytes(d));
+  LnArgs a; a.nprob = num_problems; a.d = d; a.eps = 0.f; a.ws = static_cast<float*>(workspace);
   int total = 0;
+  long long total_rows = 0;
   for (int i = 0; i < num_problems; ++i) {
     const mmf_ln_problem& p = problems[i];
     if (p.rows <= 0 || !p.x || !p.dy || !p.dx || !p.gamma || !p.mean || !p.rstd || !p.dgamma || !p.dbeta)
       MMF_FAIL(MMF_E_SHAPE, "mmf_layernorm_bwd_grouped[%d]: null operand or rows=%d", i, p.rows);
     if (!mmf_aligned16(p.x) || !mmf_aligned16(p.dy) || !mmf_aligned16(p.dx) || !mmf_aligned16(p.gamma))
       MMF_FAIL(MMF_E_ALIGN, "mmf_layernorm_bwd_grouped[%d]: pointers must be 16-byte aligned", i);
-    a.blk_start[i] = total;
-    int nb = (p.rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
-    if (nb > 256) nb = 256;                       // <= 256 blocks x d atomics per problem
-    total += nb;
     a.p[i] = p;
+    total_rows += p.rows;
+  }
+  // Workgroups are shared out over the problems in proportion to their rows (~2 per CU in total);
+  // each leaves one row of column partials in the workspace (same-row float atomics would run ~14x
+  // below the streaming rate: MI355X_MICROARCH.md, Global float atomics), summed by the finalize pass.
+  const int budget = BWD_BLOCK_BUDGET;
+  for (int i = 0; i < num_problems; ++i) {
+    const int rows = problems[i].rows;
+    int nb = (int)(((long long)rows * budget + total_rows - 1) / total_rows);
+    const int full = (rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+    if (nb > full) nb = full;
+    if (nb < 1) nb = 1;
+    a.blk_start[i] = total;
+    total += nb;
   }
   a.blk_start[num_problems] = total;
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -238,5 +280,7 @@ extern "C" int mmf_layernorm_bwd_grouped(const mmf_ln_problem* problems, int num
     default: hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(total), dim3(256), 0, s, a); break;
   }
   MMF_CHECK_LAUNCH("mmf_layernorm_bwd_grouped");
+  hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((d + 255) / 256, num_problems), dim3(256), 0, s, a);
+  MMF_CHECK_LAUNCH("mmf_layernorm_bwd_grouped(finalize)");
   return MMF_OK;
 }

@@ -16,15 +16,15 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmmfusion.so")
 
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
-EPI_BIAS, EPI_RELU, EPI_MASK_AUX, EPI_ADD_AUX, EPI_ACCUM = 1, 2, 4, 8, 16
-GEMM_MAX_PROBLEMS, ATTN_MAX_PROBLEMS, LN_MAX_PROBLEMS = 24, 12, 8
+EPI_BIAS, EPI_RELU, EPI_MASK_AUX, EPI_ADD_AUX, EPI_ACCUM, EPI_COLSUM_A = 1, 2, 4, 8, 16, 32
+GEMM_MAX_PROBLEMS, ATTN_MAX_PROBLEMS, LN_MAX_PROBLEMS, COLSUM_MAX_PROBLEMS = 24, 12, 8, 24
 
 # every symbol include/mmfusion.h declares (tests check the .so exports all of them)
 SYMBOLS = (
     "mmf_version", "mmf_last_error", "mmf_device_cu_count", "mmf_gemm_grouped",
     "mmf_attn_fwd_grouped", "mmf_attn_bwd_grouped", "mmf_layernorm_fwd_grouped",
-    "mmf_layernorm_bwd_grouped", "mmf_cast_f32_to_bf16", "mmf_cast_bf16_to_f32", "mmf_add3_bf16",
-    "mmf_meanpool_fwd", "mmf_meanpool_bwd", "mmf_colsum_bf16", "mmf_relu_bwd_bf16",
+    "mmf_layernorm_bwd_grouped", "mmf_layernorm_bwd_workspace_bytes", "mmf_cast_f32_to_bf16", "mmf_cast_bf16_to_f32", "mmf_add3_bf16",
+    "mmf_meanpool_fwd", "mmf_meanpool_bwd", "mmf_colsum_bf16", "mmf_colsum_grouped", "mmf_relu_bwd_bf16",
 )
 
 
@@ -48,6 +48,10 @@ class LnProblem(C.Structure):
                 ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("rows", C.c_int32)]
 
 
+class ColsumProblem(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("out", C.c_void_p), ("M", C.c_int32), ("N", C.c_int32), ("ldx", C.c_int32)]
+
+
 _lib: Optional[C.CDLL] = None
 
 
@@ -68,13 +72,16 @@ def load() -> C.CDLL:
     lib.mmf_attn_fwd_grouped.argtypes = [C.POINTER(AttnProblem), i32, i32, f32, vp]
     lib.mmf_attn_bwd_grouped.argtypes = [C.POINTER(AttnProblem), i32, i32, f32, vp]
     lib.mmf_layernorm_fwd_grouped.argtypes = [C.POINTER(LnProblem), i32, i32, f32, vp]
-    lib.mmf_layernorm_bwd_grouped.argtypes = [C.POINTER(LnProblem), i32, i32, vp]
+    lib.mmf_layernorm_bwd_grouped.argtypes = [C.POINTER(LnProblem), i32, i32, vp, C.c_size_t, vp]
+    lib.mmf_layernorm_bwd_workspace_bytes.argtypes = [i32]
+    lib.mmf_layernorm_bwd_workspace_bytes.restype = C.c_size_t
     lib.mmf_cast_f32_to_bf16.argtypes = [vp, vp, i64, vp]
     lib.mmf_cast_bf16_to_f32.argtypes = [vp, vp, i64, vp]
     lib.mmf_add3_bf16.argtypes = [vp, vp, vp, vp, i64, vp]
     lib.mmf_meanpool_fwd.argtypes = [vp, vp, i32, i32, i32, i32, vp]
     lib.mmf_meanpool_bwd.argtypes = [vp, vp, i32, i32, i32, i32, vp]
     lib.mmf_colsum_bf16.argtypes = [vp, vp, i32, i32, i32, vp]
+    lib.mmf_colsum_grouped.argtypes = [C.POINTER(ColsumProblem), i32, vp]
     lib.mmf_relu_bwd_bf16.argtypes = [vp, vp, vp, i64, vp]
     for name in SYMBOLS:
         getattr(lib, name)          # AttributeError here = header and .so disagree
@@ -95,19 +102,51 @@ def stream_ptr() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+# ---- optional launch timing (bench.py's roofline leg) --------------------------------------------
+# When PROFILE is a list, every grouped GEMM / attention launch is bracketed by HIP events recorded
+# on the launch stream and appended as (kernel label, algorithmic flops, start, end).
+PROFILE: Optional[list] = None
+_LAYOUT_NAME = {GEMM_NT: "NT", GEMM_NN: "NN", GEMM_TN: "TN"}
+
+
+class _Timed:
+    def __init__(self, label: str, flops: float):
+        self.label, self.flops = label, flops
+
+    def __enter__(self):
+        if PROFILE is not None:
+            import torch
+            self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.e0.record(torch.cuda.current_stream())
+        return self
+
+    def __exit__(self, *exc):
+        if PROFILE is not None:
+            import torch
+            self.e1.record(torch.cuda.current_stream())
+            PROFILE.append((self.label, self.flops, self.e0, self.e1))
+
+
 def gemm_grouped(problems: Sequence[GemmProblem], layout: int, epilogue: int, out_f32: bool) -> None:
     arr = (GemmProblem * len(problems))(*problems)
-    check(load().mmf_gemm_grouped(arr, len(problems), layout, epilogue, int(out_f32), stream_ptr()))
+    flops = sum(2.0 * p.M * p.N * p.K for p in problems) if PROFILE is not None else 0.0
+    with _Timed(f"gemm_grouped_kernel<{_LAYOUT_NAME[layout]},{'f32' if out_f32 else 'bf16'}>", flops):
+        check(load().mmf_gemm_grouped(arr, len(problems), layout, epilogue, int(out_f32), stream_ptr()))
 
 
 def attn_fwd_grouped(problems: Sequence[AttnProblem], head_dim: int, scale: float) -> None:
     arr = (AttnProblem * len(problems))(*problems)
-    check(load().mmf_attn_fwd_grouped(arr, len(problems), head_dim, scale, stream_ptr()))
+    flops = sum(4.0 * p.B * p.H * p.Tq * p.Tk * head_dim for p in problems) if PROFILE is not None else 0.0
+    with _Timed(f"attn_fwd_kernel<{head_dim}>", flops):
+        check(load().mmf_attn_fwd_grouped(arr, len(problems), head_dim, scale, stream_ptr()))
 
 
 def attn_bwd_grouped(problems: Sequence[AttnProblem], head_dim: int, scale: float) -> None:
     arr = (AttnProblem * len(problems))(*problems)
-    check(load().mmf_attn_bwd_grouped(arr, len(problems), head_dim, scale, stream_ptr()))
+    # algorithmic backward work: 4 products of 2*Tq*Tk*dh (dV, dP, dQ, dK); the recomputed S is not credited
+    flops = sum(8.0 * p.B * p.H * p.Tq * p.Tk * head_dim for p in problems) if PROFILE is not None else 0.0
+    with _Timed(f"attn_bwd_kernels<{head_dim}>", flops):
+        check(load().mmf_attn_bwd_grouped(arr, len(problems), head_dim, scale, stream_ptr()))
 
 
 def layernorm_fwd_grouped(problems: Sequence[LnProblem], d: int, eps: float) -> None:
@@ -115,6 +154,15 @@ def layernorm_fwd_grouped(problems: Sequence[LnProblem], d: int, eps: float) -> 
     check(load().mmf_layernorm_fwd_grouped(arr, len(problems), d, eps, stream_ptr()))
 
 
-def layernorm_bwd_grouped(problems: Sequence[LnProblem], d: int) -> None:
+def layernorm_bwd_grouped(problems: Sequence[LnProblem], d: int, workspace) -> None:
+    """workspace: a float32 torch tensor of >= mmf_layernorm_bwd_workspace_bytes(d) bytes."""
     arr = (LnProblem * len(problems))(*problems)
-    check(load().mmf_layernorm_bwd_grouped(arr, len(problems), d, stream_ptr()))
+    check(load().mmf_layernorm_bwd_grouped(arr, len(problems), d, workspace.data_ptr(),
+                                           workspace.numel() * workspace.element_size(), stream_ptr()))
+
+
+def colsum_grouped(problems: Sequence[ColsumProblem]) -> None:
+    for i in range(0, len(problems), COLSUM_MAX_PROBLEMS):
+        chunk = problems[i:i + COLSUM_MAX_PROBLEMS]
+        arr = (ColsumProblem * len(chunk))(*chunk)
+        check(load().mmf_colsum_grouped(arr, len(chunk), stream_ptr()))

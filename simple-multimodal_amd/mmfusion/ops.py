@@ -19,7 +19,7 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 
 from . import lib
-from .lib import (AttnProblem, GemmProblem, LnProblem, EPI_ACCUM, EPI_ADD_AUX, EPI_BIAS,
+from .lib import (AttnProblem, GemmProblem, LnProblem, EPI_ACCUM, EPI_ADD_AUX, EPI_BIAS, EPI_COLSUM_A,
                   EPI_MASK_AUX, EPI_RELU, GEMM_NN, GEMM_NT, GEMM_TN)
 
 BF16 = torch.bfloat16
@@ -118,8 +118,8 @@ def gemm_group(layout: int, probs: Sequence[tuple], epilogue: int) -> None:
             raise ValueError("aux must match C")
         if bias is not None:
             _req(bias, torch.float32)
-            if bias.numel() != N or not bias.is_contiguous():
-                raise ValueError("bias must be contiguous [N]")
+            if bias.numel() != (M if epilogue & EPI_COLSUM_A else N) or not bias.is_contiguous():
+                raise ValueError("bias must be contiguous [N] ([M] for the fused bias gradient)")
         ps.append(GemmProblem(A.data_ptr(), Bm.data_ptr(), Cm.data_ptr(),
                               bias.data_ptr() if bias is not None else None,
                               aux.data_ptr() if aux is not None else None,
@@ -221,6 +221,7 @@ class _GroupedLinear(torch.autograd.Function):
                 g = dz
             dys.append(g)
         dgrad, wgrad = [], []
+        has_bias = specs[0].b is not None
         grads: List[Optional[torch.Tensor]] = [None] * (4 * n)
         for i, s in enumerate(specs):
             g = dys[i]
@@ -230,15 +231,14 @@ class _GroupedLinear(torch.autograd.Function):
                 dx = torch.empty(xs[i].shape, dtype=BF16, device=g.device)
                 dgrad.append((g, s.w.w16, dx, None, None))
                 grads[4 * i] = dx
-            wgrad.append((g, xs[i], s.w.grad, None, None))
-            if s.b is not None:
-                lib.check(L.mmf_colsum_bf16(g.data_ptr(), s.b.grad.data_ptr(), g.shape[0], g.shape[1], _ld(g), st))
+            # wgrad; the bias gradient (column sums of dy) rides along in the same kernel
+            wgrad.append((g, xs[i], s.w.grad, s.b.grad if has_bias else None, None))
             if s.has_residual:
                 grads[4 * i + 1] = g
         if dgrad:
             gemm_group(GEMM_NN, dgrad, 0)
         if wgrad:
-            gemm_group(GEMM_TN, wgrad, EPI_ACCUM)
+            gemm_group(GEMM_TN, wgrad, EPI_ACCUM | (EPI_COLSUM_A if has_bias else 0))
         return (None, None, *grads)
 
 
@@ -258,6 +258,64 @@ def linear(x: torch.Tensor, w: W, b: Optional[W] = None, relu: bool = False,
 
 
 # --------------------------------------------------------------------------------------------
+# grouped position-wise FFN with residual:  y_i = x_i + W2_i relu(W1_i x_i + b1_i) + b2_i
+# (reference models/fusion_layers.py:195-200,208-209 before norm2).  Fused so that the backward can
+# apply the ReLU mask and the residual-gradient add in the dgrad GEMM epilogues:
+#   dH = (dY W2) * (h > 0)        NN GEMM, MASK_AUX epilogue (aux = h)
+#   dX = dH W1 + dY               NN GEMM, ADD_AUX epilogue  (aux = dY)
+# --------------------------------------------------------------------------------------------
+class _GroupedFFN(torch.autograd.Function):
+    """tensors = [x_0, W1_0, b1_0, W2_0, b2_0, x_1, ...] (parameters passed so autograd runs backward)."""
+
+    @staticmethod
+    def forward(ctx, layers, *tensors):
+        n = len(layers)
+        xs = [tensors[5 * i] for i in range(n)]
+        for x in xs:
+            _req(x, BF16)
+        hs = [torch.empty((x.shape[0], l1.weight.shape[0]), dtype=BF16, device=x.device) for x, (l1, _) in zip(xs, layers)]
+        gemm_group(GEMM_NT, [(x, l1.weight._mmf_bf16, h, l1.bias.detach(), None)
+                             for x, h, (l1, _) in zip(xs, hs, layers)], EPI_BIAS | EPI_RELU)
+        ys = [torch.empty_like(x) for x in xs]
+        gemm_group(GEMM_NT, [(h, l2.weight._mmf_bf16, y, l2.bias.detach(), x)
+                             for x, h, y, (_, l2) in zip(xs, hs, ys, layers)], EPI_BIAS | EPI_ADD_AUX)
+        ctx.layers = layers
+        ctx.save_for_backward(*xs, *hs)
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *gys):
+        layers = ctx.layers
+        n = len(layers)
+        xs, hs = ctx.saved_tensors[:n], ctx.saved_tensors[n:]
+        idx = [i for i, g in enumerate(gys) if g is not None]
+        dys = {i: gys[i].contiguous() for i in idx}
+        dhs = {i: torch.empty_like(hs[i]) for i in idx}
+        dxs = {i: torch.empty_like(xs[i]) for i in idx}
+        gemm_group(GEMM_NN, [(dys[i], layers[i][1].weight._mmf_bf16, dhs[i], None, hs[i]) for i in idx], EPI_MASK_AUX)
+        gemm_group(GEMM_NN, [(dhs[i], layers[i][0].weight._mmf_bf16, dxs[i], None, dys[i]) for i in idx], EPI_ADD_AUX)
+        gemm_group(GEMM_TN, [(dys[i], hs[i], layers[i][1].weight.grad, layers[i][1].bias.grad, None) for i in idx] +
+                   [(dhs[i], xs[i], layers[i][0].weight.grad, layers[i][0].bias.grad, None) for i in idx],
+                   EPI_ACCUM | EPI_COLSUM_A)
+        grads: List[Optional[torch.Tensor]] = [None] * (5 * n)
+        for i in idx:
+            grads[5 * i] = dxs[i]
+        return (None, *grads)
+
+
+def ffn_residual_group(items: Sequence[tuple]) -> List[torch.Tensor]:
+    """items: (x_bf16 [M, d], linear1 (d -> 4d), linear2 (4d -> d)); returns x + ffn(x) per item."""
+    layers, tensors = [], []
+    for x, l1, l2 in items:
+        for p in (l1.weight, l1.bias, l2.weight, l2.bias):
+            if getattr(p, "_mmf_bf16", None) is None or p.grad is None:
+                raise RuntimeError("FFN parameters are not arena-managed: call mmfusion.arena.ensure(module)")
+        layers.append((l1, l2))
+        tensors += [x, l1.weight, l1.bias, l2.weight, l2.bias]
+    return list(_GroupedFFN.apply(layers, *tensors))
+
+
+# --------------------------------------------------------------------------------------------
 # grouped LayerNorm
 # --------------------------------------------------------------------------------------------
 class _GroupedLayerNorm(torch.autograd.Function):
@@ -267,11 +325,12 @@ class _GroupedLayerNorm(torch.autograd.Function):
     def forward(ctx, eps: float, *tensors):
         n = len(tensors) // 3
         d = tensors[0].shape[-1]
-        outs, stats, probs = [], [], []
+        outs, stats, probs, keep = [], [], [], []
         for i in range(n):
             x, g, b = tensors[3 * i:3 * i + 3]
             _req(x, BF16)
             x = x.contiguous()
+            keep.append(x)
             rows = x.numel() // d
             y = torch.empty_like(x)
             st = torch.empty((2, rows), dtype=torch.float32, device=x.device)
@@ -290,12 +349,13 @@ class _GroupedLayerNorm(torch.autograd.Function):
         n, d = ctx.n, ctx.d
         xs, stats = ctx.saved_tensors[:n], ctx.saved_tensors[n:]
         grads: List[Optional[torch.Tensor]] = [None] * (3 * n)
-        probs = []
+        probs, keep = [], []
         for i, g in enumerate(gys):
             if g is None:
                 continue
             g = g.contiguous()
             x = xs[i].contiguous()
+            keep += [g, x]
             gamma, beta = ctx.params[i]
             if gamma.grad is None or beta.grad is None:
                 raise RuntimeError("LayerNorm parameters have no arena gradient")
@@ -305,8 +365,11 @@ class _GroupedLayerNorm(torch.autograd.Function):
                                    stats[i][1].data_ptr(), g.data_ptr(), dx.data_ptr(),
                                    gamma.grad.data_ptr(), beta.grad.data_ptr(), rows))
             grads[3 * i] = dx
+        ws_bytes = lib.load().mmf_layernorm_bwd_workspace_bytes(d)
         for i in range(0, len(probs), lib.LN_MAX_PROBLEMS):
-            lib.layernorm_bwd_grouped(probs[i:i + lib.LN_MAX_PROBLEMS], d)
+            ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=xs[0].device)
+            keep.append(ws)
+            lib.layernorm_bwd_grouped(probs[i:i + lib.LN_MAX_PROBLEMS], d, ws)
         return (None, *grads)
 
 
@@ -381,12 +444,13 @@ class _GroupedAttention(torch.autograd.Function):
                 continue
             full = len(covered[si]) * d == t.shape[1]
             gsrc.append(torch.empty_like(t) if full else torch.zeros_like(t))
-        probs = []
-        for i, (s, g) in enumerate(zip(specs, gos)):
-            if g is None:
+        probs, keep = [], []          # `keep`: every temporary whose pointer sits in a problem table must
+        for i, (s, g) in enumerate(zip(specs, gos)):      # outlive the launch, or the caching allocator
+            if g is None:                                 # hands its block to the next problem
                 continue
             g = g.contiguous()
             delta = torch.empty_like(lses[i])
+            keep += [g, delta]
             qs, ks, vs = srcs[s.q[0]], srcs[s.k[0]], srcs[s.v[0]]
             probs.append(AttnProblem(qs.data_ptr() + 2 * s.q[1], ks.data_ptr() + 2 * s.k[1], vs.data_ptr() + 2 * s.v[1],
                                      outs[i].data_ptr(), lses[i].data_ptr(), g.data_ptr(), delta.data_ptr(),

@@ -125,8 +125,7 @@ def _cross_blocks(blocks: Sequence["CrossModalTransformer"], qs: Sequence[torch.
     pre1 = ops.linear_group([(att[i], _lin(blk.attention.out_proj), qs[i]) for i, blk in enumerate(blocks)])
     x = ops.layernorm_group([(pre1[i], blk.norm1.weight, blk.norm1.bias) for i, blk in enumerate(blocks)],
                             blocks[0].norm1.eps)
-    h = ops.linear_group([(x[i], _lin(blk.ffn[0], relu=True), None) for i, blk in enumerate(blocks)])
-    pre2 = ops.linear_group([(h[i], _lin(blk.ffn[3]), x[i]) for i, blk in enumerate(blocks)])
+    pre2 = ops.ffn_residual_group([(x[i], blk.ffn[0], blk.ffn[3]) for i, blk in enumerate(blocks)])
     return ops.layernorm_group([(pre2[i], blk.norm2.weight, blk.norm2.bias) for i, blk in enumerate(blocks)],
                                blocks[0].norm2.eps)
 

@@ -84,4 +84,10 @@ def oracle_fwd_bwd(meta, P=None, inputs=None):
 def rel_err(a, b):
     """max |a-b| / max(|b|) — error relative to the tensor's scale."""
     a, b = a.detach().float().cpu(), b.detach().float().cpu()
-    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+    return float((a - b).abs().max() / max(float(b.abs().max()), 1e-6))
+
+
+def l2_rel(a, b):
+    """||a-b||_2 / ||b||_2"""
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return float((a - b).norm() / max(float(b.norm()), 1e-12))

@@ -10,8 +10,8 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from mmfusion import lib, ops  # noqa: E402
-from mmfusion.lib import (EPI_ACCUM, EPI_ADD_AUX, EPI_BIAS, EPI_MASK_AUX, EPI_RELU, GEMM_NN, GEMM_NT,
-                          GEMM_TN)  # noqa: E402
+from mmfusion.lib import (EPI_ACCUM, EPI_ADD_AUX, EPI_BIAS, EPI_COLSUM_A, EPI_MASK_AUX, EPI_RELU, GEMM_NN,
+                          GEMM_NT, GEMM_TN)  # noqa: E402
 
 DEV = "cuda"
 
@@ -25,9 +25,11 @@ def bf(x):
     return x.to(torch.bfloat16).to(DEV)
 
 
-def rel(a, b):
-    a, b = a.float().cpu(), b.float().cpu()
-    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+def rel(a, b, floor=1e-3):
+    """max |a-b| relative to the reference's scale (floored: an exactly-zero reference, e.g. dQ of a
+    one-key softmax, is compared absolutely)."""
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return float((a - b).abs().max() / max(float(b.abs().max()), floor))
 
 
 # ---------------------------------------------------------------------------------------- GEMM
@@ -76,6 +78,18 @@ def test_gemm_tn_wgrad(M, N, K):
     ops.gemm(GEMM_TN, a16, b16, C, epilogue=EPI_ACCUM)
     ops.gemm(GEMM_TN, a16, b16, C, epilogue=EPI_ACCUM)
     assert rel(C, 2 * (a16.float().cpu().t() @ b16.float().cpu())) < 1e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(768, 768, 1000), (200, 72, 100), (3072, 768, 30), (8, 2304, 515)])
+def test_gemm_tn_fused_bias_grad(M, N, K):
+    """wgrad + bias gradient in one launch: bias[m] += sum_k A[k][m]"""
+    A, B_ = rnd(K, M, seed=7), rnd(K, N, seed=8, scale=K ** -0.5)
+    a16, b16 = bf(A), bf(B_)
+    C = torch.zeros((M, N), device=DEV)
+    db = torch.full((M,), 2.0, device=DEV)
+    ops.gemm(GEMM_TN, a16, b16, C, bias=db, epilogue=EPI_ACCUM | EPI_COLSUM_A)
+    assert rel(C, a16.float().cpu().t() @ b16.float().cpu()) < 1e-5
+    assert rel(db, a16.float().cpu().sum(0) + 2.0) < 1e-5
 
 
 def test_gemm_identity_asymmetric():
