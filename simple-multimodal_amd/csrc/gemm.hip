@@ -20,6 +20,7 @@
 // tile t+1's loads are issued before tile t's MFMAs and written to the other buffer after them,
 // one barrier per k-step.
 #include "mmf_internal.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -240,6 +241,16 @@ int launch(const GemmArgs& a, int total_tiles, int out_f32, hipStream_t s) {
 
 }  // namespace
 
+int mmf_gemm2_launch(const mmf_gemm_problem* problems, int num_problems, int layout, int epilogue,
+                     int out_f32, hipStream_t s);      // gemm2.hip: LDS-DMA ring kernel
+
+// MMF_GEMM_IMPL=1 selects the register-staged 128x128 kernel of this file (kept for A/B runs);
+// default is the 256x128 LDS-DMA ring kernel of gemm2.hip.
+static int gemm_impl() {
+  static int impl = [] { const char* e = getenv("MMF_GEMM_IMPL"); return (e && e[0] == '1') ? 1 : 2; }();
+  return impl;
+}
+
 extern "C" int mmf_gemm_grouped(const mmf_gemm_problem* problems, int num_problems, int layout,
                                 int epilogue, int out_f32, void* stream) {
   if (!problems || num_problems <= 0 || num_problems > MMF_GEMM_MAX_PROBLEMS)
@@ -253,6 +264,7 @@ extern "C" int mmf_gemm_grouped(const mmf_gemm_problem* problems, int num_proble
     MMF_FAIL(MMF_E_UNSUPPORTED, "mmf_gemm_grouped: MASK_AUX and ADD_AUX are exclusive");
   if ((epilogue & MMF_EPI_COLSUM_A) && (layout != MMF_GEMM_TN || (epilogue & MMF_EPI_BIAS)))
     MMF_FAIL(MMF_E_UNSUPPORTED, "mmf_gemm_grouped: COLSUM_A is a TN (wgrad) epilogue and excludes BIAS");
+  const bool v2 = gemm_impl() == 2;
   GemmArgs a;
   a.nprob = num_problems;
   a.epi = epilogue;
@@ -284,6 +296,7 @@ extern "C" int mmf_gemm_grouped(const mmf_gemm_problem* problems, int num_proble
   }
   a.tile_start[num_problems] = total;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (v2) return mmf_gemm2_launch(problems, num_problems, layout, epilogue, out_f32, s);
   switch (layout) {
     case MMF_GEMM_NT: launch<false, false>(a, total, out_f32, s); break;
     case MMF_GEMM_NN: launch<false, true>(a, total, out_f32, s); break;

@@ -129,6 +129,41 @@ def gemm_group(layout: int, probs: Sequence[tuple], epilogue: int) -> None:
 
 
 # --------------------------------------------------------------------------------------------
+# deferred weight gradients
+# --------------------------------------------------------------------------------------------
+# dW = dy^T x has a tiny output (768 x 768 ... 3072 x 768) and a long reduction (B*T rows): one
+# block's wgrads are ~100 tiles, far fewer than 256 CUs.  Nothing downstream in the backward pass
+# reads dW, so every Function only *queues* its wgrad problems and one autograd end-of-backward
+# callback issues them all as grouped launches (>= 1000 tiles for MulT), bias gradients included.
+import os as _os
+
+DEFER_WGRAD = _os.environ.get("MMF_DEFER_WGRAD", "1") != "0"
+_pending_wgrad: List[tuple] = []
+
+
+def _flush_wgrad() -> None:
+    global _pending_wgrad
+    pend, _pending_wgrad = _pending_wgrad, []
+    with_bias = [p for p in pend if p[3] is not None]
+    without = [p for p in pend if p[3] is None]
+    # big problems first: the tail of the launch is then made of small tiles
+    for group, epi in ((with_bias, EPI_ACCUM | EPI_COLSUM_A), (without, EPI_ACCUM)):
+        if group:
+            group.sort(key=lambda t: -(t[2].shape[0] * t[2].shape[1] * t[0].shape[0]))
+            gemm_group(GEMM_TN, group, epi)
+
+
+def queue_wgrad(dy: torch.Tensor, x: torch.Tensor, wgrad: torch.Tensor, bgrad: Optional[torch.Tensor]) -> None:
+    """wgrad (f32, [N_out, K_in]) += dy^T x ;  bgrad (f32 [N_out]) += column sums of dy."""
+    if not DEFER_WGRAD:
+        gemm_group(GEMM_TN, [(dy, x, wgrad, bgrad, None)], EPI_ACCUM | (EPI_COLSUM_A if bgrad is not None else 0))
+        return
+    if not _pending_wgrad:
+        torch.autograd.Variable._execution_engine.queue_callback(_flush_wgrad)
+    _pending_wgrad.append((dy, x, wgrad, bgrad, None))
+
+
+# --------------------------------------------------------------------------------------------
 # dtype boundary
 # --------------------------------------------------------------------------------------------
 class _ToBF16(torch.autograd.Function):
@@ -220,7 +255,7 @@ class _GroupedLinear(torch.autograd.Function):
                 lib.check(L.mmf_relu_bwd_bf16(g.data_ptr(), y.data_ptr(), dz.data_ptr(), g.numel(), st))
                 g = dz
             dys.append(g)
-        dgrad, wgrad = [], []
+        dgrad = []
         has_bias = specs[0].b is not None
         grads: List[Optional[torch.Tensor]] = [None] * (4 * n)
         for i, s in enumerate(specs):
@@ -232,13 +267,11 @@ class _GroupedLinear(torch.autograd.Function):
                 dgrad.append((g, s.w.w16, dx, None, None))
                 grads[4 * i] = dx
             # wgrad; the bias gradient (column sums of dy) rides along in the same kernel
-            wgrad.append((g, xs[i], s.w.grad, s.b.grad if has_bias else None, None))
+            queue_wgrad(g, xs[i], s.w.grad, s.b.grad if has_bias else None)
             if s.has_residual:
                 grads[4 * i + 1] = g
         if dgrad:
             gemm_group(GEMM_NN, dgrad, 0)
-        if wgrad:
-            gemm_group(GEMM_TN, wgrad, EPI_ACCUM | (EPI_COLSUM_A if has_bias else 0))
         return (None, None, *grads)
 
 
@@ -294,9 +327,9 @@ class _GroupedFFN(torch.autograd.Function):
         dxs = {i: torch.empty_like(xs[i]) for i in idx}
         gemm_group(GEMM_NN, [(dys[i], layers[i][1].weight._mmf_bf16, dhs[i], None, hs[i]) for i in idx], EPI_MASK_AUX)
         gemm_group(GEMM_NN, [(dhs[i], layers[i][0].weight._mmf_bf16, dxs[i], None, dys[i]) for i in idx], EPI_ADD_AUX)
-        gemm_group(GEMM_TN, [(dys[i], hs[i], layers[i][1].weight.grad, layers[i][1].bias.grad, None) for i in idx] +
-                   [(dhs[i], xs[i], layers[i][0].weight.grad, layers[i][0].bias.grad, None) for i in idx],
-                   EPI_ACCUM | EPI_COLSUM_A)
+        for i in idx:
+            queue_wgrad(dys[i], hs[i], layers[i][1].weight.grad, layers[i][1].bias.grad)
+            queue_wgrad(dhs[i], xs[i], layers[i][0].weight.grad, layers[i][0].bias.grad)
         grads: List[Optional[torch.Tensor]] = [None] * (5 * n)
         for i in idx:
             grads[5 * i] = dxs[i]

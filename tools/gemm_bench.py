@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""GEMM microbenchmark (GPU box): TFLOP/s of mmf_gemm_grouped per layout / shape, HIP-event timed.
+    MMF_GEMM_IMPL=1|2 python tools/gemm_bench.py"""
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "simple-multimodal_amd"))
+import torch  # noqa: E402
+from mmfusion import ops  # noqa: E402
+from mmfusion.lib import GEMM_NN, GEMM_NT, GEMM_TN, EPI_ACCUM, EPI_BIAS  # noqa: E402
+
+DEV = "cuda"
+
+
+def bench(layout, shapes, reps=20, epi=0, f32=False):
+    probs = []
+    for (M, N, K) in shapes:
+        if layout == GEMM_NT:
+            A, B = torch.randn(M, K, device=DEV).bfloat16(), torch.randn(N, K, device=DEV).bfloat16()
+        elif layout == GEMM_NN:
+            A, B = torch.randn(M, K, device=DEV).bfloat16(), torch.randn(K, N, device=DEV).bfloat16()
+        else:
+            A, B = torch.randn(K, M, device=DEV).bfloat16(), torch.randn(K, N, device=DEV).bfloat16()
+        C = torch.zeros(M, N, device=DEV, dtype=torch.float32 if f32 else torch.bfloat16)
+        bias = torch.randn(N, device=DEV) if epi & EPI_BIAS else None
+        probs.append((A, B, C, bias, None))
+    for _ in range(3):
+        ops.gemm_group(layout, probs, epi)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        ops.gemm_group(layout, probs, epi)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / reps
+    fl = sum(2.0 * M * N * K for M, N, K in shapes)
+    return us, fl / us / 1e6
+
+
+def main():
+    impl = os.environ.get("MMF_GEMM_IMPL", "2")
+    rows = [8192, 8192, 6400, 6400, 480, 480]
+    cases = [
+        ("NT 4096^3", GEMM_NT, [(4096, 4096, 4096)], 0, False),
+        ("NT 8192x3072x768", GEMM_NT, [(8192, 3072, 768)], 0, False),
+        ("NT 8192x768x3072", GEMM_NT, [(8192, 768, 3072)], 0, False),
+        ("NT 8192x768x768", GEMM_NT, [(8192, 768, 768)], 0, False),
+        ("NT ffn1 group x6", GEMM_NT, [(r, 3072, 768) for r in rows], EPI_BIAS, False),
+        ("NT ffn2 group x6", GEMM_NT, [(r, 768, 3072) for r in rows], EPI_BIAS, False),
+        ("NT outproj group x6", GEMM_NT, [(r, 768, 768) for r in rows], EPI_BIAS, False),
+        ("NN 4096^3", GEMM_NN, [(4096, 4096, 4096)], 0, False),
+        ("NN dH group x6", GEMM_NN, [(r, 3072, 768) for r in rows], 0, False),
+        ("NN dX group x6", GEMM_NN, [(r, 768, 3072) for r in rows], 0, False),
+        ("TN 4096^3", GEMM_TN, [(4096, 4096, 4096)], EPI_ACCUM, True),
+        ("TN dW1 group x6", GEMM_TN, [(3072, 768, r) for r in rows], EPI_ACCUM, True),
+        ("TN dW2 group x6", GEMM_TN, [(768, 3072, r) for r in rows], EPI_ACCUM, True),
+        ("TN dWo group x6", GEMM_TN, [(768, 768, r) for r in rows], EPI_ACCUM, True),
+    ]
+    for name, layout, shapes, epi, f32 in cases:
+        us, tf = bench(layout, shapes, epi=epi, f32=f32)
+        print(f"impl{impl} {name:24s} {us:9.1f} us  {tf:7.1f} TFLOP/s", flush=True)
+
+
+if __name__ == "__main__":
+    main()
