@@ -182,7 +182,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
-    from mmfusion import arena as arena_mod, synth
+    from mmfusion import arena as arena_mod, dp, synth
     cfg, model, xs = build(args.workload, device, rank)
     arena = arena_mod.ensure(model)
     eager_step = make_step(args.workload, model, xs, arena)
@@ -207,8 +207,7 @@ def main():
         else:
             eager_step()
         if world > 1:
-            dist.all_reduce(arena.grads, op=dist.ReduceOp.SUM)
-            arena.grads.mul_(1.0 / world)
+            dp.allreduce_grads(arena)          # bucketed RCCL all-reduce (mean) of the flat gradient arena
 
     for _ in range(args.warmup):
         run_step()

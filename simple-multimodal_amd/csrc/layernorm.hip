@@ -183,20 +183,27 @@ void ln_bwd_kernel(const LnArgs a) {
   }
 }
 
-// second phase: dgamma[j] += sum over the problem's workgroups of their partials (thread = column)
+// second phase: dgamma[j] += sum over the problem's workgroups of their partials.  thread = column,
+// blockIdx.z = one of FIN_SLICES slices of the workgroup range; each slice ends in one f32 atomic per
+// column (FIN_SLICES adders per address).
+constexpr int FIN_SLICES = 8;
 __global__ __launch_bounds__(256)
 void ln_bwd_finalize_kernel(const LnArgs a) {
   const int pi = blockIdx.y;
   const int col = blockIdx.x * 256 + threadIdx.x;
   if (col >= a.d) return;
+  const int b0 = a.blk_start[pi], nb = a.blk_start[pi + 1] - b0;
+  const int per = (nb + FIN_SLICES - 1) / FIN_SLICES;
+  const int lo = b0 + blockIdx.z * per, hi = min(b0 + nb, lo + per);
+  if (lo >= hi) return;
   float sg = 0.f, sb = 0.f;
-  for (int b = a.blk_start[pi]; b < a.blk_start[pi + 1]; ++b) {
+  for (int b = lo; b < hi; ++b) {
     const float* w = a.ws + (size_t)b * 2 * a.d;
     sg += w[col];
     sb += w[a.d + col];
   }
-  a.p[pi].dgamma[col] += sg;
-  a.p[pi].dbeta[col] += sb;
+  atomicAdd(a.p[pi].dgamma + col, sg);
+  atomicAdd(a.p[pi].dbeta + col, sb);
 }
 
 int check_common(const char* who, const mmf_ln_problem* p, int n, int d) {
@@ -280,7 +287,7 @@ extern "C" int mmf_layernorm_bwd_grouped(const mmf_ln_problem* problems, int num
     default: hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(total), dim3(256), 0, s, a); break;
   }
   MMF_CHECK_LAUNCH("mmf_layernorm_bwd_grouped");
-  hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((d + 255) / 256, num_problems), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((d + 255) / 256, num_problems, FIN_SLICES), dim3(256), 0, s, a);
   MMF_CHECK_LAUNCH("mmf_layernorm_bwd_grouped(finalize)");
   return MMF_OK;
 }

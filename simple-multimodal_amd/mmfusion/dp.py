@@ -1,0 +1,74 @@
+"""Data-parallel exchange for the fusion path: one process per GPU, parameters replicated, batch
+sharded; the only collective is the mean all-reduce of the flat fp32 gradient arena
+(``ParamArena.grads``) — RCCL over xGMI when the process group's backend is ``nccl``, gloo on CPU
+in the tests.  The reference has no distributed code at all; this is the
+MI355X-native addition of SURVEY.md section 8(e).
+
+xGMI is point-to-point (7 links x ~153 GB/s per GPU), so ring all-reduce is per-link bound:
+few, large buckets (default 64 MiB) keep every link streaming and still let the first buckets
+start while the rest of backward runs (``allreduce_flat_async`` + ``wait``).
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+DEFAULT_BUCKET_BYTES = 64 << 20
+
+
+def bucket_bounds(numel: int, elem_size: int, bucket_bytes: int = DEFAULT_BUCKET_BYTES) -> List[tuple]:
+    """[(start, end)) element ranges covering [0, numel), each at most bucket_bytes, 64-element aligned."""
+    per = max(64, (bucket_bytes // elem_size) // 64 * 64)
+    return [(s, min(numel, s + per)) for s in range(0, numel, per)]
+
+
+class _Pending:
+    def __init__(self, flat, works, world, average):
+        self.flat, self.works, self.world, self.average = flat, works, world, average
+
+    def wait(self) -> None:
+        for w in self.works:
+            w.wait()
+        if self.average and self.world > 1:
+            self.flat.mul_(1.0 / self.world)
+
+
+def allreduce_flat_async(flat: torch.Tensor, group=None, average: bool = True,
+                         bucket_bytes: int = DEFAULT_BUCKET_BYTES) -> _Pending:
+    """Start bucketed SUM all-reduces of a flat contiguous tensor; ``.wait()`` finishes and averages."""
+    if flat.dim() != 1 or not flat.is_contiguous():
+        raise ValueError("allreduce_flat expects a flat contiguous tensor (the gradient arena)")
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    works = []
+    if world > 1:
+        for s, e in bucket_bounds(flat.numel(), flat.element_size(), bucket_bytes):
+            works.append(dist.all_reduce(flat[s:e], op=dist.ReduceOp.SUM, group=group, async_op=True))
+    return _Pending(flat, works, world, average)
+
+
+def allreduce_flat(flat: torch.Tensor, group=None, average: bool = True,
+                   bucket_bytes: int = DEFAULT_BUCKET_BYTES) -> None:
+    allreduce_flat_async(flat, group, average, bucket_bytes).wait()
+
+
+def allreduce_grads(arena, group=None, bucket_bytes: int = DEFAULT_BUCKET_BYTES) -> None:
+    """Mean all-reduce of every parameter gradient of a ``mmfusion.arena.ParamArena`` in place."""
+    allreduce_flat(arena.grads, group, True, bucket_bytes)
+
+
+def broadcast_params(arena, src: int = 0, group=None) -> None:
+    """Make the replicas identical (rank ``src``'s masters win), then refresh the bf16 shadow."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.broadcast(arena.master, src=src, group=group)
+    arena.refresh(force=True)
+
+
+def shard_batch(x: torch.Tensor, rank: int, world: int) -> torch.Tensor:
+    """Rows [rank*B/world, (rank+1)*B/world) of a batch-first tensor (B must divide evenly)."""
+    B = x.shape[0]
+    if B % world:
+        raise ValueError(f"global batch {B} is not divisible by world size {world}")
+    per = B // world
+    return x[rank * per:(rank + 1) * per]

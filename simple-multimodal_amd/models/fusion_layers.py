@@ -130,13 +130,20 @@ def _cross_blocks(blocks: Sequence["CrossModalTransformer"], qs: Sequence[torch.
                                blocks[0].norm2.eps)
 
 
-def _self_attention(mhas: Sequence[_MHAParams], xs: Sequence[torch.Tensor], B: int, Ts: Sequence[int]
-                    ) -> List[torch.Tensor]:
-    """n independent self-attention MHAs without residual/LN (reference :161-163)."""
+def _self_attention_core(mhas: Sequence[_MHAParams], xs: Sequence[torch.Tensor], B: int, Ts: Sequence[int]
+                         ) -> List[torch.Tensor]:
+    """packed QKV projection + fused attention of n independent self-attention MHAs; the
+    out-projection is left to the caller."""
     d, H, dh = mhas[0].embed_dim, mhas[0].num_heads, mhas[0].head_dim
     qkv = ops.linear_group([(x, m.qkv_spec(), None) for m, x in zip(mhas, xs)])
     specs = [AttnSpec(B, Ts[i], Ts[i], q=(i, 0), k=(i, d), v=(i, 2 * d)) for i in range(len(mhas))]
-    att = ops.attention_group(specs, H, dh, qkv)
+    return ops.attention_group(specs, H, dh, qkv)
+
+
+def _self_attention(mhas: Sequence[_MHAParams], xs: Sequence[torch.Tensor], B: int, Ts: Sequence[int]
+                    ) -> List[torch.Tensor]:
+    """n independent self-attention MHAs without residual/LN (reference :161-163)."""
+    att = _self_attention_core(mhas, xs, B, Ts)
     return ops.linear_group([(att[i], _lin(m.out_proj), None) for i, m in enumerate(mhas)])
 
 
@@ -241,9 +248,16 @@ class MultimodalTransformer(_FusionBase):
             blocks, [t, t, a, a, v, v], [a, v, t, v, t, a], B, [Tt, Tt, Ta, Ta, Tv, Tv],
             [Ta, Tv, Tt, Tv, Tt, Ta])                                           # :146-153
         et, ea, ev = ops.add3(t, t_a, t_v), ops.add3(a, a_t, a_v), ops.add3(v, v_t, v_a)   # :156-158
-        ta, aa, va = _self_attention([self.text_self_attn, self.audio_self_attn, self.video_self_attn],
-                                     [et, ea, ev], B, [Tt, Ta, Tv])             # :161-163
-        pooled = ops.meanpool_cat([ta.view(B, Tt, d), aa.view(B, Ta, d), va.view(B, Tv, d)])  # :166-171
+        # :161-168.  The self-attention outputs are only ever used through their mean over T, and the
+        # out-projection is affine, so mean_t(out_proj(o_t)) == out_proj(mean_t o_t): pool the attention
+        # output first and run the three out-projections on (B, d) instead of (B*T, d) rows — the same
+        # arithmetic up to fp reassociation, minus 2*(Tt+Ta+Tv)*d^2 FLOP/sample forward and twice that backward.
+        mhas = [self.text_self_attn, self.audio_self_attn, self.video_self_attn]
+        att = _self_attention_core(mhas, [et, ea, ev], B, [Tt, Ta, Tv])
+        pooled_att = ops.meanpool_cat([att[0].view(B, Tt, d), att[1].view(B, Ta, d), att[2].view(B, Tv, d)])
+        proj = ops.linear_group([(pooled_att[:, i * d:(i + 1) * d], _lin(m.out_proj), None)
+                                 for i, m in enumerate(mhas)])
+        pooled = torch.cat(proj, dim=-1)                                        # :171  (B, 3d) bf16
         fused = ops.linear(pooled, *_wb(self.final_fusion[0]), relu=True, out_f32=True)       # :172
         pf = ops.to_f32(pooled)
         return {"fused_features": fused, "text_features": pf[:, :d], "audio_features": pf[:, d:2 * d],
