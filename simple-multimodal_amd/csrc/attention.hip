@@ -257,7 +257,7 @@ void attn_fwd_kernel(const AttnArgs a) {
 //   S^T = K.Q^T, P^T = exp(S^T*scale - LSE), dP^T = V.dO^T, dS^T = P^T (dP^T - delta), dQ^T += K^T.dS^T
 // ================================================================================================
 template <int DH>
-__global__ __launch_bounds__(NT)
+__global__ __launch_bounds__(NT, 2)      // 2 workgroups per CU: <= 256 VGPR+AGPR per lane
 void attn_bwd_dq_kernel(const AttnArgs a) {
   constexpr int KS = DH / 16, DT = DH / 32;
   constexpr int TILE_B = 64 * (DH + 8) * 2;
@@ -373,7 +373,7 @@ void attn_bwd_dq_kernel(const AttnArgs a) {
 //   dK^T += Q^T.dS
 // ================================================================================================
 template <int DH>
-__global__ __launch_bounds__(NT)
+__global__ __launch_bounds__(NT, 2)      // 2 workgroups per CU: <= 256 VGPR+AGPR per lane
 void attn_bwd_dkv_kernel(const AttnArgs a) {
   constexpr int KS = DH / 16, DT = DH / 32;
   constexpr int TILE_B = 64 * (DH + 8) * 2;
@@ -432,11 +432,6 @@ void attn_bwd_dkv_kernel(const AttnArgs a) {
   int cur = 0;
   for (int j = 0; j < ntiles; ++j) {
     const bool more = j + 1 < ntiles;
-    if (more) {
-      sq.load(Qg, P.ldq, (j + 1) * 64, Tq, tid);
-      sdo.load(dOg, P.ldo, (j + 1) * 64, Tq, tid);
-      load_stat((j + 1) * 64);
-    }
     const char* sQ = smem + cur * 2 * TILE_B;
     const char* sdO = sQ + TILE_B;
     const float* sl = sstat + cur * 128;
@@ -475,7 +470,10 @@ void attn_bwd_dkv_kernel(const AttnArgs a) {
         }
       }
     }
-    if (more) {
+    if (more) {       // the next Q/dO tile is fetched here, not ahead of the MFMAs: holding it in registers
+      sq.load(Qg, P.ldq, (j + 1) * 64, Tq, tid);       // across the compute phase costs 25 VGPRs and
+      sdo.load(dOg, P.ldo, (j + 1) * 64, Tq, tid);     // the second workgroup on the CU (<= 256
+      load_stat((j + 1) * 64);                         // registers) hides this latency better
       char* d = smem + (cur ^ 1) * 2 * TILE_B;
       sq.store(d, tid);
       sdo.store(d + TILE_B, tid);

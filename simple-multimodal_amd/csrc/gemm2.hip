@@ -115,10 +115,18 @@ void gemm2_grouped_kernel(const GemmArgs args, const int total_tiles) {
   while (pi + 1 < args.nprob && bid >= args.tile_start[pi + 1]) ++pi;
   const mmf_gemm_problem& P = args.p[pi];
   const int M = P.M, N = P.N, K = P.K;
-  const int tiles_m = (M + BM - 1) / BM;
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   const int t = bid - args.tile_start[pi];
-  const int m0 = (t % tiles_m) * BM;
-  const int n0 = (t / tiles_m) * BN;
+  // Super-rows of GROUP_M m-tiles, n fastest across a super-row: the ~32 tiles an XCD runs at the same
+  // time then form a GROUP_M x 4 block of the output and share A and B panels in that XCD's L2; with a
+  // plain m-fastest order they would be 32 different m-tiles of one n-tile (no A reuse: every A slice
+  // would stream from the Infinity Cache at ~1/2 the L2 rate).
+  constexpr int GROUP_M = 8;
+  const int grp = t / (GROUP_M * tiles_n), rem = t % (GROUP_M * tiles_n);
+  const int gm = min(GROUP_M, tiles_m - grp * GROUP_M);
+  const int m0 = (grp * GROUP_M + rem % gm) * BM;
+  const int n0 = (rem / gm) * BN;
+  (void)tiles_n;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
