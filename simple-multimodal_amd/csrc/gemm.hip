@@ -244,11 +244,21 @@ int launch(const GemmArgs& a, int total_tiles, int out_f32, hipStream_t s) {
 int mmf_gemm2_launch(const mmf_gemm_problem* problems, int num_problems, int layout, int epilogue,
                      int out_f32, hipStream_t s);      // gemm2.hip: LDS-DMA ring kernel
 
-// MMF_GEMM_IMPL=1 selects the register-staged 128x128 kernel of this file (kept for A/B runs);
-// default is the 256x128 LDS-DMA ring kernel of gemm2.hip.
-static int gemm_impl() {
-  static int impl = [] { const char* e = getenv("MMF_GEMM_IMPL"); return (e && e[0] == '1') ? 1 : 2; }();
-  return impl;
+int mmf_gemm3_launch(const mmf_gemm_problem* problems, int num_problems, int layout, int epilogue,
+                     int out_f32, hipStream_t s);      // gemm3.hip: persistent LDS-DMA ring kernel
+
+// Implementation switch (A/B runs in one process: tools/gemm_bench.py): 1 = register-staged 128x128
+// kernel of this file, 2 = 256x128 LDS-DMA ring (gemm2.hip), 3 = its persistent form (gemm3.hip).
+// Default from MMF_GEMM_IMPL, else 2.
+static int g_gemm_impl = [] {
+  const char* e = getenv("MMF_GEMM_IMPL");
+  return (e && e[0] >= '1' && e[0] <= '3') ? e[0] - '0' : 2;
+}();
+static int gemm_impl() { return g_gemm_impl; }
+extern "C" int mmf_gemm_select_impl(int impl) {
+  if (impl < 1 || impl > 3) MMF_FAIL(MMF_E_UNSUPPORTED, "mmf_gemm_select_impl: %d not in 1..3", impl);
+  g_gemm_impl = impl;
+  return MMF_OK;
 }
 
 extern "C" int mmf_gemm_grouped(const mmf_gemm_problem* problems, int num_problems, int layout,
@@ -264,7 +274,7 @@ extern "C" int mmf_gemm_grouped(const mmf_gemm_problem* problems, int num_proble
     MMF_FAIL(MMF_E_UNSUPPORTED, "mmf_gemm_grouped: MASK_AUX and ADD_AUX are exclusive");
   if ((epilogue & MMF_EPI_COLSUM_A) && (layout != MMF_GEMM_TN || (epilogue & MMF_EPI_BIAS)))
     MMF_FAIL(MMF_E_UNSUPPORTED, "mmf_gemm_grouped: COLSUM_A is a TN (wgrad) epilogue and excludes BIAS");
-  const bool v2 = gemm_impl() == 2;
+  const int impl = gemm_impl();
   GemmArgs a;
   a.nprob = num_problems;
   a.epi = epilogue;
@@ -296,7 +306,14 @@ extern "C" int mmf_gemm_grouped(const mmf_gemm_problem* problems, int num_proble
   }
   a.tile_start[num_problems] = total;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (v2) return mmf_gemm2_launch(problems, num_problems, layout, epilogue, out_f32, s);
+  if (impl == 2) return mmf_gemm2_launch(problems, num_problems, layout, epilogue, out_f32, s);
+  if (impl == 3) {
+    bool wide_ok = true;              // the persistent kernel only has the 16-byte bf16 epilogue
+    for (int i = 0; i < num_problems && !out_f32; ++i)
+      wide_ok = wide_ok && !(problems[i].N & 7) && !(problems[i].ldc & 7);
+    if (wide_ok) return mmf_gemm3_launch(problems, num_problems, layout, epilogue, out_f32, s);
+    return mmf_gemm2_launch(problems, num_problems, layout, epilogue, out_f32, s);
+  }
   switch (layout) {
     case MMF_GEMM_NT: launch<false, false>(a, total, out_f32, s); break;
     case MMF_GEMM_NN: launch<false, true>(a, total, out_f32, s); break;

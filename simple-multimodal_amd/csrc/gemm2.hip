@@ -178,12 +178,9 @@ void gemm2_grouped_kernel(const GemmArgs args, const int total_tiles) {
     else             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                  // every wave's pieces landed; stage (kt+2)%3 is free
     asm volatile("" ::: "memory");
-    if (kt + 2 < nk) issue_tile(kt + 2);
-
     const char* sA = smem + (kt % STAGES) * STAGE_BYTES;
     const char* sB = sA + A_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    auto compute = [&](int ks) {
       bf16x8_t fm[4], fn[4];
       s16x4_t nlo[4], nhi[4], mlo[4], mhi[4];
 #pragma unroll
@@ -214,7 +211,16 @@ void gemm2_grouped_kernel(const GemmArgs args, const int total_tiles) {
         for (int tm = 0; tm < 4; ++tm)
           csum[tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fm[tm], csum[tm], 0, 0, 0);
       }
-    }
+    };
+    // Role split (guide "Two waves per SIMD", item 9): waves w and w+4 share a SIMD and would otherwise
+    // run in lockstep behind the barrier — both issuing their six LDS-DMA pieces, then both reading
+    // fragments, then both issuing MFMAs.  Waves 0-3 prefetch before their MFMAs, waves 4-7 between
+    // the two k-substeps, so one wave's DMA issue and fragment reads overlap its partner's MFMAs.
+    const bool want_prefetch = kt + 2 < nk;
+    if (want_prefetch && wave < 4) issue_tile(kt + 2);
+    compute(0);
+    if (want_prefetch && wave >= 4) issue_tile(kt + 2);
+    compute(1);
   }
 
   if (A_KR && do_colsum) {              // every MFMA row holds the same sums: take row 0 (lanes 0..15, reg 0)
@@ -230,37 +236,77 @@ void gemm2_grouped_kernel(const GemmArgs args, const int total_tiles) {
   // ---- epilogue: lane owns C[m][n..n+3] for each of its 16 MFMA tiles -------------------------------
   const int epi = args.epi;
   const unsigned short* __restrict__ aux = static_cast<const unsigned short*>(P.aux);
+  auto finish = [&](f32x4_t v, int m, int n) -> f32x4_t {          // bias -> relu -> mask -> residual
+    if (epi & MMF_EPI_BIAS) v += *reinterpret_cast<const f32x4_t*>(P.bias + n);
+    if (epi & MMF_EPI_RELU) {
 #pragma unroll
-  for (int tm = 0; tm < 4; ++tm) {
-    const int m = m0 + wm + tm * 16 + (lane & 15);
-    if (m >= M) continue;
-#pragma unroll
-    for (int tn = 0; tn < 4; ++tn) {
-      const int n = n0 + wn + tn * 16 + ((lane >> 4) << 2);
-      if (n >= N) continue;
-      f32x4_t v = acc[tn][tm];
-      if (epi & MMF_EPI_BIAS) v += *reinterpret_cast<const f32x4_t*>(P.bias + n);
-      if (epi & MMF_EPI_RELU) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+      for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+    }
+    if (epi & (MMF_EPI_MASK_AUX | MMF_EPI_ADD_AUX)) {
+      const u32x2_t a = *reinterpret_cast<const u32x2_t*>(aux + (size_t)m * P.ldaux + n);
+      const float a0 = bf16lo(a[0]), a1 = bf16hi(a[0]), a2 = bf16lo(a[1]), a3 = bf16hi(a[1]);
+      if (epi & MMF_EPI_MASK_AUX) {
+        v[0] = a0 > 0.f ? v[0] : 0.f; v[1] = a1 > 0.f ? v[1] : 0.f;
+        v[2] = a2 > 0.f ? v[2] : 0.f; v[3] = a3 > 0.f ? v[3] : 0.f;
       }
-      if (epi & (MMF_EPI_MASK_AUX | MMF_EPI_ADD_AUX)) {
-        const u32x2_t a = *reinterpret_cast<const u32x2_t*>(aux + (size_t)m * P.ldaux + n);
-        const float a0 = bf16lo(a[0]), a1 = bf16hi(a[0]), a2 = bf16lo(a[1]), a3 = bf16hi(a[1]);
-        if (epi & MMF_EPI_MASK_AUX) {
-          v[0] = a0 > 0.f ? v[0] : 0.f; v[1] = a1 > 0.f ? v[1] : 0.f;
-          v[2] = a2 > 0.f ? v[2] : 0.f; v[3] = a3 > 0.f ? v[3] : 0.f;
-        }
-        if (epi & MMF_EPI_ADD_AUX) { v[0] += a0; v[1] += a1; v[2] += a2; v[3] += a3; }
-      }
-      if (OUT_F32) {
+      if (epi & MMF_EPI_ADD_AUX) { v[0] += a0; v[1] += a1; v[2] += a2; v[3] += a3; }
+    }
+    return v;
+  };
+  if (OUT_F32) {
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm) {
+      const int m = m0 + wm + tm * 16 + (lane & 15);
+      if (m >= M) continue;
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) {
+        const int n = n0 + wn + tn * 16 + ((lane >> 4) << 2);
+        if (n >= N) continue;
+        f32x4_t v = finish(acc[tn][tm], m, n);
         float* c = static_cast<float*>(P.C) + (size_t)m * P.ldc + n;
         if (epi & MMF_EPI_ACCUM) v += *reinterpret_cast<const f32x4_t*>(c);
         *reinterpret_cast<f32x4_t*>(c) = v;
-      } else {
-        unsigned short* c = static_cast<unsigned short*>(P.C) + (size_t)m * P.ldc + n;
+      }
+    }
+  } else if ((N & 7) == 0 && (P.ldc & 7) == 0) {
+    // bf16 output, 16-byte stores (guide T21): the tail of a short-K tile is store-ISSUE bound, so the
+    // 8-byte pieces of two neighbouring MFMA column tiles are exchanged between the lane groups
+    // g = lane>>4 and g^1 with v_permlane16_swap; even groups then hold 8 consecutive columns of tile
+    // tn, odd groups of tile tn+1: 8 store instructions per wave instead of 16, same bytes and lines.
+    const int g = lane >> 4;
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm) {
+      const int m = m0 + wm + tm * 16 + (lane & 15);
+#pragma unroll
+      for (int tp = 0; tp < 2; ++tp) {
+        const int nA = n0 + wn + (2 * tp) * 16 + (g << 2), nB = nA + 16;
+        const bool okA = m < M && nA < N, okB = m < M && nB < N;
+        f32x4_t va = acc[2 * tp][tm], vb = acc[2 * tp + 1][tm];
+        if (okA) va = finish(va, m, nA);
+        if (okB) vb = finish(vb, m, nB);
+        unsigned a0 = pack_bf16x2(va[0], va[1]), a1 = pack_bf16x2(va[2], va[3]);
+        unsigned b0 = pack_bf16x2(vb[0], vb[1]), b1 = pack_bf16x2(vb[2], vb[3]);
+        const auto r0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
+        const auto r1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+        // even g: {own tile-A cols 4g..4g+3 | group g+1's tile-A cols}; odd g: {group g-1's tile-B | own tile-B}
+        const u32x4_t o = {r0[0], r1[0], r0[1], r1[1]};
+        const int n = (g & 1) ? nB - 4 : nA;
+        if (m < M && n < N)
+          *reinterpret_cast<u32x4_t*>(static_cast<unsigned short*>(P.C) + (size_t)m * P.ldc + n) = o;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm) {
+      const int m = m0 + wm + tm * 16 + (lane & 15);
+      if (m >= M) continue;
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) {
+        const int n = n0 + wn + tn * 16 + ((lane >> 4) << 2);
+        if (n >= N) continue;
+        const f32x4_t v = finish(acc[tn][tm], m, n);
         const u32x2_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-        *reinterpret_cast<u32x2_t*>(c) = o;
+        *reinterpret_cast<u32x2_t*>(static_cast<unsigned short*>(P.C) + (size_t)m * P.ldc + n) = o;
       }
     }
   }

@@ -40,12 +40,13 @@ def bench(layout, shapes, reps=20, epi=0, f32=False):
 
 
 def main():
-    impl = os.environ.get("MMF_GEMM_IMPL", "2")
+    from mmfusion import lib
+    L = lib.load()
+    impls = [int(x) for x in os.environ.get("IMPLS", "2,3").split(",")]
     rows = [8192, 8192, 6400, 6400, 480, 480]
     cases = [
         ("NT 4096^3", GEMM_NT, [(4096, 4096, 4096)], 0, False),
         ("NT 8192x3072x768", GEMM_NT, [(8192, 3072, 768)], 0, False),
-        ("NT 8192x768x3072", GEMM_NT, [(8192, 768, 3072)], 0, False),
         ("NT 8192x768x768", GEMM_NT, [(8192, 768, 768)], 0, False),
         ("NT ffn1 group x6", GEMM_NT, [(r, 3072, 768) for r in rows], EPI_BIAS, False),
         ("NT ffn2 group x6", GEMM_NT, [(r, 768, 3072) for r in rows], EPI_BIAS, False),
@@ -55,12 +56,18 @@ def main():
         ("NN dX group x6", GEMM_NN, [(r, 768, 3072) for r in rows], 0, False),
         ("TN 4096^3", GEMM_TN, [(4096, 4096, 4096)], EPI_ACCUM, True),
         ("TN dW1 group x6", GEMM_TN, [(3072, 768, r) for r in rows], EPI_ACCUM, True),
-        ("TN dW2 group x6", GEMM_TN, [(768, 3072, r) for r in rows], EPI_ACCUM, True),
         ("TN dWo group x6", GEMM_TN, [(768, 768, r) for r in rows], EPI_ACCUM, True),
     ]
+    rounds = int(os.environ.get("ROUNDS", "3"))
     for name, layout, shapes, epi, f32 in cases:
-        us, tf = bench(layout, shapes, epi=epi, f32=f32)
-        print(f"impl{impl} {name:24s} {us:9.1f} us  {tf:7.1f} TFLOP/s", flush=True)
+        best = {i: 0.0 for i in impls}
+        for _ in range(rounds):                       # interleaved rounds in ONE process (guide rule 24)
+            for i in impls:
+                lib.check(L.mmf_gemm_select_impl(i))
+                us, tf = bench(layout, shapes, reps=10, epi=epi, f32=f32)
+                best[i] = max(best[i], tf)
+        print(f"{name:24s} " + "  ".join(f"impl{i} {best[i]:7.1f} TF" for i in impls), flush=True)
+    lib.check(L.mmf_gemm_select_impl(2))
 
 
 if __name__ == "__main__":
