@@ -138,6 +138,29 @@ def cpu_baseline(workload):
                       f"steps ({best:.2f} s/step) on {model_name}"}
 
 
+_SYMBOL = {"gemm_grouped_kernel<NT,bf16>": "gemm2_grouped_kernel<false, false, false>",
+           "gemm_grouped_kernel<NT,f32>": "gemm2_grouped_kernel<false, false, true>",
+           "gemm_grouped_kernel<NN,bf16>": "gemm2_grouped_kernel<false, true, false>",
+           "gemm_grouped_kernel<TN,f32>": "gemm2_grouped_kernel<true, true, true>",
+           "attn_fwd_kernel<96>": "attn_fwd_kernel<96>"}
+
+
+def pmc_traffic(label):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes
+    (profiles/*_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of this
+    same workload, FETCH_SIZE x2 for gfx950).  bench.py cannot profile itself, hence the file; None if absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "*_pmc_traffic.json")))
+    if not files or label not in _SYMBOL:
+        return None
+    try:
+        with open(files[-1]) as f:
+            k = json.load(f)["kernels"].get(_SYMBOL[label])
+        return int(k["hbm_bytes_per_launch"]) if k else None
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def kernel_profile(step, nsteps):
     """Eager pass with HIP events around every grouped GEMM / attention launch."""
     from mmfusion import lib
@@ -164,6 +187,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=5)
+    ap.add_argument("--allreduce", choices=["bf16", "fp32"], default="bf16",
+                    help="wire dtype of the gradient all-reduce for N > 1 (compute and accumulation stay as is)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -207,7 +232,8 @@ def main():
         else:
             eager_step()
         if world > 1:
-            dp.allreduce_grads(arena)          # bucketed RCCL all-reduce (mean) of the flat gradient arena
+            # bucketed RCCL all-reduce (mean) of the flat gradient arena
+            dp.allreduce_grads(arena, compress=None if args.allreduce == "fp32" else "bf16")
 
     for _ in range(args.warmup):
         run_step()
@@ -237,7 +263,7 @@ def main():
         dsec = prof[dom]["ms_total"] * 1e-3
         ach = prof[dom]["flops_total"] / dsec / 1e12
         roofline = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": BF16_MFMA_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic(dom),
                     "avg_launch_us": round(prof[dom]["ms_total"] * 1e3 / prof[dom]["launches"], 2),
                     "launches_per_step": prof[dom]["launches"] // args.profile_steps}
         kernels = {k: {"us_per_step": round(v["ms_total"] * 1e3 / args.profile_steps, 1),
@@ -252,6 +278,7 @@ def main():
             "config": {"workload": f"{'MulT' if args.workload == 'mult' else 'hier-seq'} fwd+bwd, B=16/GPU, "
                                    f"T_text=512 T_audio=400 T_frames=30 d=768 H=8, fusion_dropout=0",
                        "global_batch": B * world, "parallelism": f"dp{world}",
+                       "grad_allreduce": (args.allreduce if world > 1 else None),
                        "graph_replay": bool(use_graph)},
             "step_tflops": round(3 * fwd_flops * B / (ms_per_step * 1e-3) / 1e12, 1) if args.workload == "mult" else None,
             "roofline": roofline,

@@ -112,33 +112,35 @@ void relu_bwd_kernel(const unsigned short* __restrict__ dy, const unsigned short
   }
 }
 
-// mean over T: grid (B, ceil(d/512)); lane -> 8 columns, the 4 waves split T, LDS combine.
+// mean over T: grid (B, ceil(d/128)); a workgroup owns 128 columns of one sample: 16 lanes x 8 columns
+// (one 256-byte segment per row), 16 row groups walk T, LDS combine.  B * d/128 workgroups (96 for
+// B=16, d=768) instead of B * d/512.
 __global__ __launch_bounds__(256)
 void meanpool_fwd_kernel(const unsigned short* __restrict__ x, unsigned short* __restrict__ y,
                          int T, int d, int ldy) {
-  __shared__ float red[3][512];
-  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int col = (blockIdx.y * 64 + lane) * 8;
+  __shared__ float red[16][128 + 4];
+  const int b = blockIdx.x, cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const int col = blockIdx.y * 128 + cl * 8;
   float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (col < d) {
     const unsigned short* p = x + (size_t)b * T * d + col;
-    for (int t = wave; t < T; t += 4) {
+    for (int t = rg; t < T; t += 16) {
       const u32x4_t w = *reinterpret_cast<const u32x4_t*>(p + (size_t)t * d);
       s[0] += bf16lo(w[0]); s[1] += bf16hi(w[0]); s[2] += bf16lo(w[1]); s[3] += bf16hi(w[1]);
       s[4] += bf16lo(w[2]); s[5] += bf16hi(w[2]); s[6] += bf16lo(w[3]); s[7] += bf16hi(w[3]);
     }
   }
-  if (wave > 0) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) red[wave - 1][lane * 8 + e] = s[e];
-  }
+  for (int e = 0; e < 8; ++e) red[rg][cl * 8 + e] = s[e];
   __syncthreads();
-  if (wave == 0 && col < d) {
-    const float inv = 1.f / (float)T;
+  if (threadIdx.x < 128) {
+    const int c = blockIdx.y * 128 + threadIdx.x;
+    if (c < d) {
+      float t = 0.f;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) s[e] = (s[e] + red[0][lane * 8 + e] + red[1][lane * 8 + e] + red[2][lane * 8 + e]) * inv;
-    u32x4_t o = {pack_bf16x2(s[0], s[1]), pack_bf16x2(s[2], s[3]), pack_bf16x2(s[4], s[5]), pack_bf16x2(s[6], s[7])};
-    *reinterpret_cast<u32x4_t*>(y + (size_t)b * ldy + col) = o;
+      for (int g = 0; g < 16; ++g) t += red[g][threadIdx.x];
+      y[(size_t)b * ldy + c] = f32_to_bf16_bits(t / (float)T);
+    }
   }
 }
 
@@ -250,7 +252,7 @@ extern "C" int mmf_meanpool_fwd(const void* x, void* y, int B, int T, int d, int
   if (B <= 0 || T <= 0 || d <= 0 || (d & 7) || (ldy & 7) || ldy < d)
     MMF_FAIL(MMF_E_SHAPE, "mmf_meanpool_fwd: B=%d T=%d d=%d ldy=%d (d, ldy multiples of 8)", B, T, d, ldy);
   EW_PTR_CHECK("mmf_meanpool_fwd", x && y && mmf_aligned16(x) && mmf_aligned16(y));
-  hipLaunchKernelGGL(meanpool_fwd_kernel, dim3(B, (d + 511) / 512), dim3(256), 0, static_cast<hipStream_t>(stream),
+  hipLaunchKernelGGL(meanpool_fwd_kernel, dim3(B, (d + 127) / 128), dim3(256), 0, static_cast<hipStream_t>(stream),
                      static_cast<const unsigned short*>(x), static_cast<unsigned short*>(y), T, d, ldy);
   MMF_CHECK_LAUNCH("mmf_meanpool_fwd");
   return MMF_OK;

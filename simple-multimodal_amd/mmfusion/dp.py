@@ -53,9 +53,37 @@ def allreduce_flat(flat: torch.Tensor, group=None, average: bool = True,
     allreduce_flat_async(flat, group, average, bucket_bytes).wait()
 
 
-def allreduce_grads(arena, group=None, bucket_bytes: int = DEFAULT_BUCKET_BYTES) -> None:
-    """Mean all-reduce of every parameter gradient of a ``mmfusion.arena.ParamArena`` in place."""
-    allreduce_flat(arena.grads, group, True, bucket_bytes)
+def allreduce_grads(arena, group=None, bucket_bytes: int = DEFAULT_BUCKET_BYTES,
+                    compress: Optional[str] = None) -> None:
+    """Mean all-reduce of every parameter gradient of a ``mmfusion.arena.ParamArena`` in place.
+
+    ``compress="bf16"`` sends bf16 over the wire: grads (fp32) -> bf16 wire buffer (the HIP cast kernel),
+    bucketed SUM all-reduce in bf16, -> fp32, * 1/world.  Halves the bytes on xGMI (103 MB instead of
+    206 MB for MulT at d=768); each rank's contribution is rounded to 8 significant bits once and the
+    ring sums in bf16, the usual trade of bf16 gradient compression.  Default (None) is exact fp32."""
+    if compress is None:
+        allreduce_flat(arena.grads, group, True, bucket_bytes)
+        return
+    if compress != "bf16":
+        raise ValueError("compress must be None or 'bf16'")
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return
+    wire = getattr(arena, "_wire_bf16", None)
+    if wire is None or wire.numel() != arena.grads.numel():
+        wire = torch.empty(arena.grads.numel(), dtype=torch.bfloat16, device=arena.grads.device)
+        arena._wire_bf16 = wire
+    if arena.grads.is_cuda:
+        from . import lib
+        L, st = lib.load(), lib.stream_ptr()
+        lib.check(L.mmf_cast_f32_to_bf16(arena.grads.data_ptr(), wire.data_ptr(), wire.numel(), st))
+        allreduce_flat(wire, group, False, bucket_bytes)
+        lib.check(L.mmf_cast_bf16_to_f32(wire.data_ptr(), arena.grads.data_ptr(), wire.numel(), lib.stream_ptr()))
+    else:                                   # CPU (gloo tests): same arithmetic with torch casts
+        wire.copy_(arena.grads)
+        allreduce_flat(wire, group, False, bucket_bytes)
+        arena.grads.copy_(wire)
+    arena.grads.mul_(1.0 / world)
 
 
 def broadcast_params(arena, src: int = 0, group=None) -> None:

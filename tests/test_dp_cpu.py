@@ -42,7 +42,13 @@ def _worker(rank, world, port, q):
     err = float((mine - full).abs().max() / full.abs().max())
     avg = torch.full((1000,), float(rank + 1))
     dp.allreduce_flat(avg, average=True, bucket_bytes=1024)        # mean of 1 and 2
-    q.put((rank, err, float(avg.min()), float(avg.max())))
+    # bf16-compressed path on an arena-shaped object: mean of the two shard gradients, 2^-8 accurate
+    from types import SimpleNamespace
+    shard = _flat_grads(P, [dp.shard_batch(x, rank, world) for x in xs], 2)
+    fake = SimpleNamespace(grads=shard.clone())
+    dp.allreduce_grads(fake, compress="bf16", bucket_bytes=100_000)
+    cerr = float((fake.grads - full / world).abs().max() / (full / world).abs().max())
+    q.put((rank, err, float(avg.min()), float(avg.max()), cerr))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -58,9 +64,10 @@ def test_two_rank_gradient_allreduce_matches_full_batch():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, err, lo, hi in res:
+    for rank, err, lo, hi, cerr in res:
         assert err < 1e-5, f"rank {rank}: all-reduced gradient deviates by {err}"
         assert lo == hi == 1.5
+        assert cerr < 2 ** -6, f"rank {rank}: bf16-compressed all-reduce deviates by {cerr}"
 
 
 def test_bucket_bounds_cover_exactly():
