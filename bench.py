@@ -53,16 +53,53 @@ def build(workload, device, rank):
     import config as cfgmod
     from mmfusion import synth
     from models import fusion_layers as fl
+    from models.multimodal_model import EmotionClassifier
     S = synth.C2_SHAPES
     cfg = cfgmod.ModelConfig()
     cfg.fusion_hidden_size, cfg.fusion_num_heads, cfg.fusion_dropout = S["d"], S["heads"], 0.0
     cfg.graph_hidden_size, cfg.graph_num_layers, cfg.graph_dropout = S["d"], 3, 0.0
     torch.manual_seed(synth.WEIGHT_SEED)
-    model = (fl.MultimodalTransformer if workload == "mult" else fl.HierarchicalFusion)(cfg)
+    if workload == "train":
+        class FusionWithHead(fl._FusionBase):          # one arena over fusion + classifier head
+            def __init__(self):
+                super().__init__()
+                self.fusion_layer = fl.HierarchicalFusion(cfg)
+                self.classifier = EmotionClassifier(cfg)
+
+            def forward(self, t, a, v, compute_contrastive_loss=False):
+                out = dict(self.fusion_layer(t, a, v, compute_contrastive_loss=compute_contrastive_loss))
+                out["emotion_logits"] = self.classifier(out["fused_features"])
+                return out
+        model = FusionWithHead()
+    else:
+        model = (fl.MultimodalTransformer if workload == "mult" else fl.HierarchicalFusion)(cfg)
     model = model.to(device).train()
     xs = [t.to(device) for t in synth.make_features(S["B"], (S["T_text"], S["T_audio"], S["T_frames"]), S["d"],
                                                     seed=synth.INPUT_SEED + rank)]
     return cfg, model, xs
+
+
+def make_train_step(model, xs, arena, world, allreduce, rank):
+    """hierarchical-fusion TRAINING step (BASELINE configs[3]): zero grads, forward, CE(ls=0.1) + 0.1 *
+    contrastive, backward | RCCL all-reduce | clip(1.0) + AdamW (fused, also refreshes the bf16 shadow)."""
+    from mmfusion import dp
+    from mmfusion.train import FusedAdamW, fusion_loss, one_cycle_lr
+    opt = FusedAdamW(arena, lr=1e-4, weight_decay=1e-5, max_grad_norm=1.0)
+    g = torch.Generator().manual_seed(99 + rank)
+    labels = torch.randint(0, 7, (xs[0].shape[0],), generator=g).to(xs[0].device)
+
+    def fwd_bwd():
+        arena.zero_grad()
+        out = model(*xs, compute_contrastive_loss=True)
+        fusion_loss(out, labels).backward()
+
+    def before_replay():
+        opt.set_hparams(lr=one_cycle_lr(opt.t, 100000, 1e-4))
+
+    def exchange():
+        if world > 1:
+            dp.allreduce_grads(arena, compress=None if allreduce == "fp32" else "bf16")
+    return fwd_bwd, before_replay, exchange, opt.launch
 
 
 def make_step(workload, model, xs, arena):
@@ -183,7 +220,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", choices=["mult", "hier"], default="mult")
+    ap.add_argument("--workload", choices=["mult", "hier", "train"], default="mult",
+                    help="mult: MulT fwd+bwd (BASELINE configs[1], the headline); hier: hier-seq fwd+bwd "
+                         "(configs[2]); train: hier-seq training step incl. fused clip+AdamW (configs[3])")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=5)
@@ -210,23 +249,49 @@ def main():
     from mmfusion import arena as arena_mod, dp, synth
     cfg, model, xs = build(args.workload, device, rank)
     arena = arena_mod.ensure(model)
-    eager_step = make_step(args.workload, model, xs, arena)
-
     use_graph = not args.no_graph
-    graph = None
-    if use_graph:
+    graph = graph2 = None
+
+    def capture(fn):
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(3):
-                eager_step()
+                fn()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            eager_step()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            fn()
+        return g
 
-    def run_step():
+    if args.workload == "train":
+        fwd_bwd, before_replay, exchange, opt_launch = make_train_step(model, xs, arena, world, args.allreduce, rank)
+
+        def eager_step():
+            before_replay()
+            fwd_bwd()
+            exchange()
+            opt_launch()
+        if use_graph:                       # two graphs: the all-reduce sits between backward and AdamW
+            before_replay()
+            graph = capture(fwd_bwd)
+            graph2 = capture(opt_launch)
+
+        def run_step():
+            if graph is not None:
+                before_replay()
+                graph.replay()
+                exchange()
+                graph2.replay()
+            else:
+                eager_step()
+    else:
+        eager_step = make_step(args.workload, model, xs, arena)
+        if use_graph:
+            graph = capture(eager_step)
+
+    def run_step_fwdbwd():
         if graph is not None:
             graph.replay()
         else:
@@ -234,6 +299,8 @@ def main():
         if world > 1:
             # bucketed RCCL all-reduce (mean) of the flat gradient arena
             dp.allreduce_grads(arena, compress=None if args.allreduce == "fp32" else "bf16")
+    if args.workload != "train":
+        run_step = run_step_fwdbwd
 
     for _ in range(args.warmup):
         run_step()
@@ -275,8 +342,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
             "data": "synthetic",
-            "config": {"workload": f"{'MulT' if args.workload == 'mult' else 'hier-seq'} fwd+bwd, B=16/GPU, "
-                                   f"T_text=512 T_audio=400 T_frames=30 d=768 H=8, fusion_dropout=0",
+            "config": {"workload": {"mult": "MulT fwd+bwd", "hier": "hier-seq fwd+bwd",
+                                    "train": "hier-seq training step (fwd+bwd+clip+AdamW)"}[args.workload] +
+                                   ", B=16/GPU, T_text=512 T_audio=400 T_frames=30 d=768 H=8, fusion_dropout=0",
                        "global_batch": B * world, "parallelism": f"dp{world}",
                        "grad_allreduce": (args.allreduce if world > 1 else None),
                        "graph_replay": bool(use_graph)},
@@ -284,7 +352,7 @@ def main():
             "roofline": roofline,
             "kernels": kernels,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == "mult":
             line["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -176,6 +176,19 @@ int mmf_colsum_grouped(const mmf_colsum_problem* problems, int num_problems, voi
 /* relu backward on bf16: dx = dy * (y > 0) */
 int mmf_relu_bwd_bf16(const void* dy, const void* y, void* dx, int64_t n, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Training-step tail on the flat arenas (reference recipe training/advanced_trainer.py:85-110,
+ * 168-182: clip_grad_norm_(1.0) then AdamW).  out[0] += sum x^2 ;  AdamW with decoupled weight
+ * decay, optional global-norm clipping from the device scalar gnorm_sq (NULL or hparams[7] <= 0:
+ * none) and a gradient scale, updating the fp32 masters AND the bf16 shadow in one pass.
+ * hparams is a DEVICE array of 9 floats: lr, beta1, beta2, eps, weight_decay, 1-beta1^t,
+ * 1-beta2^t, max_grad_norm, grad_scale (device-resident so a captured graph can be replayed with
+ * new values).
+ * ------------------------------------------------------------------------------------------ */
+int mmf_sqnorm_f32(const float* x, int64_t n, float* out, void* stream);
+int mmf_adamw_step(float* master, const float* grad, float* exp_avg, float* exp_avg_sq, void* shadow_bf16,
+                   int64_t n, const float* hparams, const float* gnorm_sq, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -16,6 +16,7 @@
 // conflict-free, the transposed operands come from the same image via ds_read_b64_tr_b16.
 // Softmax runs in the exp2 domain in f32; masked (>= Tk) keys get -1e30.
 #include "mmf_internal.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -27,6 +28,7 @@ constexpr float NEG_BIG = -1.0e30f;
 struct AttnArgs {
   int nprob;
   float scale;
+  int debug;      // timing ablations (MMF_ATTN_DEBUG, results wrong by design): 1 no exp, 2 no PV, 4 no QK, 8 no K/V reload
   int blk_start[MMF_ATTN_MAX_PROBLEMS + 1];
   mmf_attn_problem p[MMF_ATTN_MAX_PROBLEMS];
 };
@@ -123,6 +125,48 @@ __device__ __forceinline__ void store_rows(const f32x16_t (&o)[DH / 32], float m
     }
 }
 
+// ---- whole-row HBM access through a wave-private LDS slice ------------------------------------------
+// Fragment-shaped loads / stores (lane = row) touch 32 rows x 32 B (loads) or 32 rows x 8 B (stores) per
+// instruction: 32+ cache lines each, and the 8-byte pieces make partial-line writes.  For small
+// attention problems that prologue/epilogue is most of the kernel.  Instead a wave moves its 32 rows as
+// 16-byte chunks in row-major order (12 lanes per 192-B row) and converts to/from the MFMA fragment
+// layout in a [32][DH+8] LDS slice it owns (LDS ops of one wave execute in order: no barrier needed).
+template <int DH>
+__device__ __forceinline__ void load_row_frags_lds(bf16x8_t (&f)[DH / 16], const unsigned short* __restrict__ base,
+                                                   int ld, int row0, int T, int lane, char* slice) {
+  constexpr int CPR = DH / 8, SB = (DH + 8) * 2, N = 32 * CPR / 64;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const int c = lane + 64 * i, row = c / CPR, ch = c % CPR;
+    u32x4_t v = {0u, 0u, 0u, 0u};
+    if (row0 + row < T) v = *reinterpret_cast<const u32x4_t*>(base + (size_t)(row0 + row) * ld + ch * 8);
+    *reinterpret_cast<u32x4_t*>(slice + row * SB + ch * 16) = v;
+  }
+#pragma unroll
+  for (int ks = 0; ks < DH / 16; ++ks) f[ks] = row_frag<DH>(slice, 0, ks, lane);
+}
+
+template <int DH>
+__device__ __forceinline__ void store_rows_lds(const f32x16_t (&o)[DH / 32], float mul, unsigned short* __restrict__ base,
+                                               int ld, int row0, int T, int lane, char* slice) {
+  constexpr int CPR = DH / 8, SB = (DH + 8) * 2, N = 32 * CPR / 64;
+  char* p = slice + (lane & 31) * SB + 8 * (lane >> 5);
+#pragma unroll
+  for (int dt = 0; dt < DH / 32; ++dt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const u32x2_t w = {pack_bf16x2(o[dt][4 * g + 0] * mul, o[dt][4 * g + 1] * mul),
+                         pack_bf16x2(o[dt][4 * g + 2] * mul, o[dt][4 * g + 3] * mul)};
+      *reinterpret_cast<u32x2_t*>(p + (32 * dt + 8 * g) * 2) = w;
+    }
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const int c = lane + 64 * i, row = c / CPR, ch = c % CPR;
+    const u32x4_t v = *reinterpret_cast<const u32x4_t*>(slice + row * SB + ch * 16);
+    if (row0 + row < T) *reinterpret_cast<u32x4_t*>(base + (size_t)(row0 + row) * ld + ch * 8) = v;
+  }
+}
+
 __device__ __forceinline__ int find_problem(const AttnArgs& a, int bid) {
   int pi = 0;
   while (pi + 1 < a.nprob && bid >= a.blk_start[pi + 1]) ++pi;
@@ -153,8 +197,11 @@ void attn_fwd_kernel(const AttnArgs a) {
   const unsigned short* Kg = static_cast<const unsigned short*>(P.K) + (size_t)b * Tk * P.ldk + h * DH;
   const unsigned short* Vg = static_cast<const unsigned short*>(P.V) + (size_t)b * Tk * P.ldv + h * DH;
 
+  // wave-private [32][DH+8] slice inside ring buffer 1: free until the first store into that buffer,
+  // which happens behind the prologue barrier below; free again after the k-loop's last barrier
+  char* slice = smem + 2 * TILE_B + wave * (32 * (DH + 8) * 2);
   bf16x8_t qf[KS];
-  load_row_frags<DH>(qf, Qg, P.ldq, q0, Tq, lane);
+  load_row_frags_lds<DH>(qf, Qg, P.ldq, q0, Tq, lane, slice);
 
   f32x16_t o[DT];
 #pragma unroll
@@ -174,7 +221,7 @@ void attn_fwd_kernel(const AttnArgs a) {
 
   int cur = 0;
   for (int j = 0; j < ntiles; ++j) {
-    const bool more = j + 1 < ntiles;
+    const bool more = j + 1 < ntiles && !(a.debug & 8);
     if (more) {
       sk.load(Kg, P.ldk, (j + 1) * 64, Tk, tid);
       sv.load(Vg, P.ldv, (j + 1) * 64, Tk, tid);
@@ -188,9 +235,11 @@ void attn_fwd_kernel(const AttnArgs a) {
     for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+      if (!(a.debug & 4)) {
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks)
         s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<DH>(sK, 32 * kt, ks, lane), qf[ks], s[kt], 0, 0, 0);
+      }
     }
     // scale into the exp2 domain, mask the ragged tail, running max
     const bool ragged = kb + 64 > Tk;
@@ -212,6 +261,7 @@ void attn_fwd_kernel(const AttnArgs a) {
     const float alpha = fast_exp2(m - mnew);
     m = mnew;
     float rs = 0.f;
+    if (!(a.debug & 1)) {
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -220,12 +270,14 @@ void attn_fwd_kernel(const AttnArgs a) {
         s[kt][r] = p;
         rs += p;
       }
+    }
     l = l * alpha + rs;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
     // O^T += V^T . P^T
+    if (!(a.debug & 2))
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -247,7 +299,7 @@ void attn_fwd_kernel(const AttnArgs a) {
   l += __shfl_xor(l, 32, 64);
   const float inv = 1.f / l;
   unsigned short* Og = static_cast<unsigned short*>(P.O) + (size_t)b * Tq * P.ldo + h * DH;
-  store_rows<DH>(o, inv, Og, P.ldo, q0, Tq, lane);
+  store_rows_lds<DH>(o, inv, Og, P.ldo, q0, Tq, lane, slice);
   const int qrow = q0 + (lane & 31);
   if (half == 0 && qrow < Tq) P.LSE[(size_t)bh * Tq + qrow] = m * LN2 + __logf(l);
 }
@@ -281,14 +333,15 @@ void attn_bwd_dq_kernel(const AttnArgs a) {
   const unsigned short* Kg = static_cast<const unsigned short*>(P.K) + (size_t)b * Tk * P.ldk + h * DH;
   const unsigned short* Vg = static_cast<const unsigned short*>(P.V) + (size_t)b * Tk * P.ldv + h * DH;
 
+  char* slice = smem + 2 * TILE_B + wave * (32 * (DH + 8) * 2);     // see attn_fwd_kernel
   bf16x8_t qf[KS], dof[KS];
-  load_row_frags<DH>(qf, Qg, P.ldq, q0, Tq, lane);
-  load_row_frags<DH>(dof, dOg, P.ldo, q0, Tq, lane);
+  load_row_frags_lds<DH>(qf, Qg, P.ldq, q0, Tq, lane, slice);
+  load_row_frags_lds<DH>(dof, dOg, P.ldo, q0, Tq, lane, slice);
   // delta[q] = sum_d dO[q][d] * O[q][d]  (each half-lane pair covers the row once)
   float delta = 0.f;
   {
     bf16x8_t of[KS];
-    load_row_frags<DH>(of, Og, P.ldo, q0, Tq, lane);
+    load_row_frags_lds<DH>(of, Og, P.ldo, q0, Tq, lane, slice);
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const u32x4_t x = __builtin_bit_cast(u32x4_t, of[ks]), y = __builtin_bit_cast(u32x4_t, dof[ks]);
@@ -363,7 +416,7 @@ void attn_bwd_dq_kernel(const AttnArgs a) {
     cur ^= 1;
   }
   unsigned short* dQg = static_cast<unsigned short*>(P.dQ) + qoff;
-  store_rows<DH>(dq, a.scale, dQg, P.ldq, q0, Tq, lane);
+  store_rows_lds<DH>(dq, a.scale, dQg, P.ldq, q0, Tq, lane, slice);
 }
 
 // ================================================================================================
@@ -400,9 +453,10 @@ void attn_bwd_dkv_kernel(const AttnArgs a) {
   const float* LSEg = P.LSE + (size_t)bh * Tq;
   const float* DELg = P.delta + (size_t)bh * Tq;
 
+  char* slice = smem + 2 * TILE_B + wave * (32 * (DH + 8) * 2);     // see attn_fwd_kernel
   bf16x8_t kf[KS], vf[KS];
-  load_row_frags<DH>(kf, Kg, P.ldk, k0, Tk, lane);
-  load_row_frags<DH>(vf, Vg, P.ldv, k0, Tk, lane);
+  load_row_frags_lds<DH>(kf, Kg, P.ldk, k0, Tk, lane, slice);
+  load_row_frags_lds<DH>(vf, Vg, P.ldv, k0, Tk, lane, slice);
 
   f32x16_t dk[DT], dv[DT];
 #pragma unroll
@@ -483,8 +537,8 @@ void attn_bwd_dkv_kernel(const AttnArgs a) {
     cur ^= 1;
   }
   if (wave_active) {
-    store_rows<DH>(dk, a.scale, static_cast<unsigned short*>(P.dK) + koff, P.ldk, k0, Tk, lane);
-    store_rows<DH>(dv, 1.f, static_cast<unsigned short*>(P.dV) + voff, P.ldv, k0, Tk, lane);
+    store_rows_lds<DH>(dk, a.scale, static_cast<unsigned short*>(P.dK) + koff, P.ldk, k0, Tk, lane, slice);
+    store_rows_lds<DH>(dv, 1.f, static_cast<unsigned short*>(P.dV) + voff, P.ldv, k0, Tk, lane, slice);
   }
 }
 
@@ -511,6 +565,8 @@ int validate(const char* who, const mmf_attn_problem* p, int n, int head_dim, bo
 
 int fill_args(AttnArgs& a, const mmf_attn_problem* p, int n, float scale, bool by_keys) {
   a.nprob = n; a.scale = scale;
+  const char* dbg = getenv("MMF_ATTN_DEBUG");
+  a.debug = dbg ? atoi(dbg) : 0;
   int total = 0;
   for (int i = 0; i < n; ++i) {
     a.blk_start[i] = total;

@@ -1,0 +1,107 @@
+// Training-step tail on the flat arenas (reference recipe
+// training/advanced_trainer.py:85-110,168-182): global gradient norm, clip, AdamW — two streaming kernels
+// over the fp32 gradient / master arenas.  The AdamW kernel also writes the bf16 shadow the MFMA GEMMs
+// read, so a training step needs no separate fp32 -> bf16 weight cast.  HBM-bound: 16 B/element read
+// (p, g, m, v) + 14 B/element written (p, m, v, shadow).
+// Hyper-parameters live in a small DEVICE array so that a captured hipGraph can be replayed with a new
+// learning rate / bias correction every step (the host updates the array before the replay).
+#include "mmf_internal.h"
+
+namespace {
+
+constexpr int OPT_THREADS = 256;
+
+__global__ __launch_bounds__(OPT_THREADS)
+void sqnorm_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
+  __shared__ float red[OPT_THREADS / 64];
+  const int64_t nvec = n >> 2;
+  const int64_t stride = (int64_t)gridDim.x * OPT_THREADS;
+  float s = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * OPT_THREADS + threadIdx.x; i < nvec; i += stride) {
+    const f32x4_t v = *reinterpret_cast<const f32x4_t*>(x + i * 4);
+    s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+  }
+  if (blockIdx.x == 0) {
+    const int64_t t = (nvec << 2) + threadIdx.x;
+    if (t < n) s += x[t] * x[t];
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+// hp: [0] lr  [1] beta1  [2] beta2  [3] eps  [4] weight_decay  [5] 1-beta1^t  [6] 1-beta2^t
+//     [7] max_grad_norm (<= 0: no clipping)  [8] grad_scale (e.g. 1/world for an un-averaged all-reduce)
+__global__ __launch_bounds__(OPT_THREADS)
+void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                  float* __restrict__ v, unsigned short* __restrict__ shadow, int64_t n,
+                  const float* __restrict__ hp, const float* __restrict__ gnorm_sq) {
+  const float lr = hp[0], b1 = hp[1], b2 = hp[2], eps = hp[3], wd = hp[4], bc1 = hp[5], bc2 = hp[6];
+  float gs = hp[8];
+  if (hp[7] > 0.f && gnorm_sq) {      // torch.nn.utils.clip_grad_norm_: coef = max_norm / (norm + 1e-6), <= 1
+    const float norm = sqrtf(*gnorm_sq) * fabsf(gs);
+    gs *= fminf(1.f, hp[7] / (norm + 1e-6f));
+  }
+  const float step = lr / bc1, rs2 = rsqrtf(bc2), decay = 1.f - lr * wd;
+  const int64_t nvec = n >> 2;
+  const int64_t stride = (int64_t)gridDim.x * OPT_THREADS;
+  for (int64_t i = (int64_t)blockIdx.x * OPT_THREADS + threadIdx.x; i < nvec; i += stride) {
+    f32x4_t pp = *reinterpret_cast<const f32x4_t*>(p + i * 4);
+    const f32x4_t gg = *reinterpret_cast<const f32x4_t*>(g + i * 4);
+    f32x4_t mm = *reinterpret_cast<const f32x4_t*>(m + i * 4);
+    f32x4_t vv = *reinterpret_cast<const f32x4_t*>(v + i * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float ge = gg[e] * gs;
+      mm[e] = b1 * mm[e] + (1.f - b1) * ge;
+      vv[e] = b2 * vv[e] + (1.f - b2) * ge * ge;
+      pp[e] = pp[e] * decay - step * mm[e] / (sqrtf(vv[e]) * rs2 + eps);
+    }
+    *reinterpret_cast<f32x4_t*>(p + i * 4) = pp;
+    *reinterpret_cast<f32x4_t*>(m + i * 4) = mm;
+    *reinterpret_cast<f32x4_t*>(v + i * 4) = vv;
+    const u32x2_t sh = {pack_bf16x2(pp[0], pp[1]), pack_bf16x2(pp[2], pp[3])};
+    *reinterpret_cast<u32x2_t*>(shadow + i * 4) = sh;
+  }
+  if (blockIdx.x == 0) {
+    const int64_t t = (nvec << 2) + threadIdx.x;
+    if (t < n) {
+      const float ge = g[t] * gs;
+      const float mt = b1 * m[t] + (1.f - b1) * ge, vt = b2 * v[t] + (1.f - b2) * ge * ge;
+      const float pt = p[t] * decay - step * mt / (sqrtf(vt) * rs2 + eps);
+      p[t] = pt; m[t] = mt; v[t] = vt; shadow[t] = f32_to_bf16_bits(pt);
+    }
+  }
+}
+
+inline int opt_grid(int64_t n) {
+  int64_t g = ((n >> 2) + OPT_THREADS - 1) / OPT_THREADS;
+  if (g > 2048) g = 2048;
+  return g < 1 ? 1 : (int)g;
+}
+
+}  // namespace
+
+extern "C" int mmf_sqnorm_f32(const float* x, int64_t n, float* out, void* stream) {
+  if (n <= 0) return MMF_OK;
+  if (!x || !out || !mmf_aligned16(x)) MMF_FAIL(MMF_E_ALIGN, "mmf_sqnorm_f32: null or unaligned pointer");
+  hipLaunchKernelGGL(sqnorm_kernel, dim3(opt_grid(n)), dim3(OPT_THREADS), 0, static_cast<hipStream_t>(stream), x, n, out);
+  MMF_CHECK_LAUNCH("mmf_sqnorm_f32");
+  return MMF_OK;
+}
+
+extern "C" int mmf_adamw_step(float* master, const float* grad, float* exp_avg, float* exp_avg_sq,
+                              void* shadow_bf16, int64_t n, const float* hparams, const float* gnorm_sq,
+                              void* stream) {
+  if (n <= 0) return MMF_OK;
+  if (!master || !grad || !exp_avg || !exp_avg_sq || !shadow_bf16 || !hparams)
+    MMF_FAIL(MMF_E_SHAPE, "mmf_adamw_step: null pointer");
+  if (!mmf_aligned16(master) || !mmf_aligned16(grad) || !mmf_aligned16(exp_avg) || !mmf_aligned16(exp_avg_sq) ||
+      (reinterpret_cast<uintptr_t>(shadow_bf16) & 7))
+    MMF_FAIL(MMF_E_ALIGN, "mmf_adamw_step: arenas must be 16-byte aligned");
+  hipLaunchKernelGGL(adamw_kernel, dim3(opt_grid(n)), dim3(OPT_THREADS), 0, static_cast<hipStream_t>(stream),
+                     master, grad, exp_avg, exp_avg_sq, static_cast<unsigned short*>(shadow_bf16), n, hparams, gnorm_sq);
+  MMF_CHECK_LAUNCH("mmf_adamw_step");
+  return MMF_OK;
+}

@@ -94,9 +94,18 @@ class ParamArena:
         base = self.master.data_ptr()
         return all(p.data_ptr() == base + 4 * o for p, o in zip(self.params, self.offsets))
 
+    def mark_shadow_fresh(self) -> None:
+        """Called by ``mmfusion.train.FusedAdamW`` after its kernel has written masters AND shadow:
+        the next forward needs no cast (until some other writer touches a parameter)."""
+        self._cast_version = self._version()
+        self._shadow_fresh = True
+
     def refresh(self, force: bool = False) -> None:
         """master (fp32) -> shadow (bf16): one streaming kernel over the whole arena."""
         v = self._version()
+        if getattr(self, "_shadow_fresh", False) and v == self._cast_version:
+            return                     # the fused optimiser keeps the shadow in step with the masters
+        self._shadow_fresh = False
         if force or v != self._cast_version:
             lib.check(lib.load().mmf_cast_f32_to_bf16(self.master.data_ptr(), self.shadow.data_ptr(),
                                                       self.numel, lib.stream_ptr()))

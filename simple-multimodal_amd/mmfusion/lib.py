@@ -25,6 +25,7 @@ SYMBOLS = (
     "mmf_attn_fwd_grouped", "mmf_attn_bwd_grouped", "mmf_layernorm_fwd_grouped",
     "mmf_layernorm_bwd_grouped", "mmf_layernorm_bwd_workspace_bytes", "mmf_cast_f32_to_bf16", "mmf_cast_bf16_to_f32", "mmf_add3_bf16",
     "mmf_meanpool_fwd", "mmf_meanpool_bwd", "mmf_colsum_bf16", "mmf_colsum_grouped", "mmf_relu_bwd_bf16",
+    "mmf_sqnorm_f32", "mmf_adamw_step",
 )
 
 
@@ -83,6 +84,8 @@ def load() -> C.CDLL:
     lib.mmf_colsum_bf16.argtypes = [vp, vp, i32, i32, i32, vp]
     lib.mmf_colsum_grouped.argtypes = [C.POINTER(ColsumProblem), i32, vp]
     lib.mmf_relu_bwd_bf16.argtypes = [vp, vp, vp, i64, vp]
+    lib.mmf_sqnorm_f32.argtypes = [vp, i64, vp, vp]
+    lib.mmf_adamw_step.argtypes = [vp, vp, vp, vp, vp, i64, vp, vp, vp]
     for name in SYMBOLS:
         getattr(lib, name)          # AttributeError here = header and .so disagree
     if lib.mmf_version() != 1:

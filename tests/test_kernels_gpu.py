@@ -241,3 +241,28 @@ def test_cast_add_pool_colsum_relu():
     dx = torch.empty_like(dy)
     lib.check(L.mmf_relu_bwd_bf16(dy.data_ptr(), yv.data_ptr(), dx.data_ptr(), 999, lib.stream_ptr()))
     assert torch.equal(dx, torch.where(yv.float() > 0, dy, torch.zeros_like(dy)))
+
+
+# ---------------------------------------------------------------------------------------- optimiser
+def test_fused_adamw_matches_torch():
+    """3 steps of clip_grad_norm_(1.0) + AdamW(wd=1e-5) on a small module vs the fused arena kernels"""
+    from mmfusion import arena as arena_mod
+    from mmfusion.train import FusedAdamW
+    torch.manual_seed(0)
+    mod = torch.nn.Sequential(torch.nn.Linear(40, 72), torch.nn.Linear(72, 8)).cuda()
+    ref = torch.nn.Sequential(torch.nn.Linear(40, 72), torch.nn.Linear(72, 8))
+    ref.load_state_dict({k: v.cpu() for k, v in mod.state_dict().items()})
+    ar = arena_mod.ensure(mod)
+    opt = FusedAdamW(ar, lr=1e-2, weight_decay=1e-5, max_grad_norm=1.0)
+    ropt = torch.optim.AdamW(ref.parameters(), lr=1e-2, weight_decay=1e-5)
+    for step in range(3):
+        grads = [rnd(*p.shape, seed=100 * step + i) * 3 for i, p in enumerate(ref.parameters())]
+        for p, rp, g in zip(mod.parameters(), ref.parameters(), grads):
+            p.grad.copy_(g.to(DEV))
+            rp.grad = g.clone()
+        torch.nn.utils.clip_grad_norm_(ref.parameters(), 1.0)
+        ropt.step()
+        opt.step()
+        for p, rp in zip(mod.parameters(), ref.parameters()):
+            assert rel(p.detach(), rp.detach(), floor=1e-6) < 1e-5
+            assert rel(p._mmf_bf16, rp.detach().to(torch.bfloat16), floor=1e-6) < 2 ** -7
