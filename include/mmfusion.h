@@ -72,7 +72,11 @@ enum {
   /* TN only: additionally `bias[m] += sum_k A[k][m]` (f32 atomics) — the nn.Linear bias gradient
    * (column sums of dy) taken from the A tiles the wgrad kernel stages anyway; `bias` is then an
    * OUTPUT of length M and MMF_EPI_BIAS must not be set. */
-  MMF_EPI_COLSUM_A = 32
+  MMF_EPI_COLSUM_A = 32,
+  /* mmf_gemm_grouped_ex only: after ReLU, zero each element with probability extra->dropout_p and scale
+   * the kept ones by 1/(1-p) (nn.Dropout in training mode, reference models/fusion_layers.py:198);
+   * the mask is a stateless hash of (*extra->rng_state, extra->site, problem index, m*N+n). */
+  MMF_EPI_DROPOUT = 64
 };
 
 typedef struct mmf_gemm_problem {
@@ -87,6 +91,19 @@ typedef struct mmf_gemm_problem {
 
 int mmf_gemm_grouped(const mmf_gemm_problem* problems, int num_problems, int layout,
                      int epilogue, int out_f32, void* stream);
+/* Extended form: `alpha` multiplies the result after the mask step (before +aux / accumulate) — the
+ * 1/(1-p) of a dropout backward: dH = (dY W2) * (h_dropped > 0) * alpha needs no RNG because dropped
+ * units are exactly 0 in the saved activations.  rng_state is a DEVICE pointer to the 64-bit dropout
+ * state.  extra == NULL behaves like mmf_gemm_grouped. */
+typedef struct mmf_gemm_extra {
+  float alpha;
+  float dropout_p;
+  const uint64_t* rng_state;
+  uint32_t site;
+} mmf_gemm_extra;
+int mmf_gemm_grouped_ex(const mmf_gemm_problem* problems, int num_problems, int layout, int epilogue,
+                        int out_f32, const mmf_gemm_extra* extra, void* stream);
+
 /* Tuning hook: which kernel generation mmf_gemm_grouped dispatches to (1 register-staged 128x128,
  * 2 LDS-DMA ring 256x128 [default], 3 persistent LDS-DMA ring).  Results are identical up to f32
  * summation order; exists so that A/B timings can be interleaved inside one process. */
@@ -118,6 +135,13 @@ int mmf_attn_fwd_grouped(const mmf_attn_problem* problems, int num_problems, int
                          float scale, void* stream);
 int mmf_attn_bwd_grouped(const mmf_attn_problem* problems, int num_problems, int head_dim,
                          float scale, void* stream);
+/* With attention-probability dropout (nn.MultiheadAttention(dropout=p) in training mode): the
+ * probabilities are dropped/rescaled before P.V, the softmax normaliser uses the undropped row sums;
+ * the backward kernels regenerate the same mask from (*rng_state, site, problem, b, h, q, key). */
+int mmf_attn_fwd_grouped_ex(const mmf_attn_problem* problems, int num_problems, int head_dim, float scale,
+                            float dropout_p, const uint64_t* rng_state, uint32_t site, void* stream);
+int mmf_attn_bwd_grouped_ex(const mmf_attn_problem* problems, int num_problems, int head_dim, float scale,
+                            float dropout_p, const uint64_t* rng_state, uint32_t site, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * LayerNorm over the last dimension (eps inside the sqrt, biased variance, affine), one
@@ -173,6 +197,10 @@ typedef struct mmf_colsum_problem {
   int32_t M, N, ldx;
 } mmf_colsum_problem;
 int mmf_colsum_grouped(const mmf_colsum_problem* problems, int num_problems, void* stream);
+/* y = x * keep / (1-p) elementwise (nn.Dropout, training mode); is_f32 selects f32 or bf16 storage.
+ * The same call with the same (*rng_state, site) on dy gives the backward.  In place allowed. */
+int mmf_dropout(const void* x, void* y, int64_t n, int is_f32, float p, const uint64_t* rng_state,
+                uint32_t site, void* stream);
 /* relu backward on bf16: dx = dy * (y > 0) */
 int mmf_relu_bwd_bf16(const void* dy, const void* y, void* dx, int64_t n, void* stream);
 

@@ -29,6 +29,10 @@ struct AttnArgs {
   int nprob;
   float scale;
   int debug;      // timing ablations (MMF_ATTN_DEBUG, results wrong by design): 1 no exp, 2 no PV, 4 no QK, 8 no K/V reload
+  // attention-probability dropout (0 threshold = off): mask = hash(*rng_state, site, problem/b/h, q*Tk + key)
+  unsigned drop_thresh, site;
+  float inv_keep;
+  const unsigned long long* rng_state;
   int blk_start[MMF_ATTN_MAX_PROBLEMS + 1];
   mmf_attn_problem p[MMF_ATTN_MAX_PROBLEMS];
 };
@@ -176,7 +180,7 @@ __device__ __forceinline__ int find_problem(const AttnArgs& a, int bid) {
 // ================================================================================================
 // forward: workgroup = 128 query rows of one (b, h); wave = 32 query rows; KV tiles of 64 keys
 // ================================================================================================
-template <int DH>
+template <int DH, bool DROP>
 __global__ __launch_bounds__(NT)
 void attn_fwd_kernel(const AttnArgs a) {
   constexpr int KS = DH / 16, DT = DH / 32;
@@ -210,6 +214,9 @@ void attn_fwd_kernel(const AttnArgs a) {
     for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
   float m = NEG_BIG, l = 0.f;
   const float c = a.scale * LOG2E;
+  constexpr bool drop = DROP;
+  const unsigned dkey = drop ? mmf_rng_key(*a.rng_state, a.site, (unsigned)(pi * 4096 + bh)) : 0u;
+  const unsigned qidx = (unsigned)(q0 + (lane & 31)) * (unsigned)Tk;
 
   TileStage<DH, 64> sk, sv;
   const int ntiles = (Tk + 63) / 64;
@@ -272,6 +279,15 @@ void attn_fwd_kernel(const AttnArgs a) {
       }
     }
     l = l * alpha + rs;
+    if (drop) {              // nn.MultiheadAttention(dropout=p): drop/rescale the probabilities fed to P.V only
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const unsigned key = (unsigned)(kb + 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * half);
+          s[kt][r] = mmf_keep(dkey, qidx + key, a.drop_thresh) ? s[kt][r] * a.inv_keep : 0.f;
+        }
+    }
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -308,7 +324,7 @@ void attn_fwd_kernel(const AttnArgs a) {
 // backward, dQ (+ delta): same sweep as the forward; per KV tile
 //   S^T = K.Q^T, P^T = exp(S^T*scale - LSE), dP^T = V.dO^T, dS^T = P^T (dP^T - delta), dQ^T += K^T.dS^T
 // ================================================================================================
-template <int DH>
+template <int DH, bool DROP>
 __global__ __launch_bounds__(NT, 2)      // 2 workgroups per CU: <= 256 VGPR+AGPR per lane
 void attn_bwd_dq_kernel(const AttnArgs a) {
   constexpr int KS = DH / 16, DT = DH / 32;
@@ -353,6 +369,9 @@ void attn_bwd_dq_kernel(const AttnArgs a) {
   }
   const float c = a.scale * LOG2E;
   const float lse2 = (qrow < Tq ? P.LSE[(size_t)bh * Tq + qrow] : 0.f) * LOG2E;
+  constexpr bool drop = DROP;
+  const unsigned dkey = drop ? mmf_rng_key(*a.rng_state, a.site, (unsigned)(pi * 4096 + bh)) : 0u;
+  const unsigned qidx = (unsigned)qrow * (unsigned)Tk;
 
   f32x16_t dq[DT];
 #pragma unroll
@@ -393,11 +412,11 @@ void attn_bwd_dq_kernel(const AttnArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         float p = fast_exp2(s[r] * c - lse2);
-        if (ragged) {
-          const int key = kb + 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * half;
-          p = key < Tk ? p : 0.f;
-        }
-        s[r] = p * (dp[r] - delta);                       // dS^T (scale applied at the store)
+        const int key = kb + 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (ragged) p = key < Tk ? p : 0.f;
+        float dpv = dp[r];                                // d(P_dropped) -> dP through the same mask
+        if (drop) dpv = mmf_keep(dkey, qidx + (unsigned)key, a.drop_thresh) ? dpv * a.inv_keep : 0.f;
+        s[r] = p * (dpv - delta);                         // dS^T (scale applied at the store)
       }
 #pragma unroll
       for (int ss = 0; ss < 2; ++ss) {
@@ -425,7 +444,7 @@ void attn_bwd_dq_kernel(const AttnArgs a) {
 //   S = Q.K^T, P = exp(S*scale - LSE[q]), dV^T += dO^T.P, dP = dO.V^T, dS = P (dP - delta[q]),
 //   dK^T += Q^T.dS
 // ================================================================================================
-template <int DH>
+template <int DH, bool DROP>
 __global__ __launch_bounds__(NT, 2)      // 2 workgroups per CU: <= 256 VGPR+AGPR per lane
 void attn_bwd_dkv_kernel(const AttnArgs a) {
   constexpr int KS = DH / 16, DT = DH / 32;
@@ -464,6 +483,9 @@ void attn_bwd_dkv_kernel(const AttnArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
   const float c = a.scale * LOG2E;
+  constexpr bool drop = DROP;
+  const unsigned dkey = drop ? mmf_rng_key(*a.rng_state, a.site, (unsigned)(pi * 4096 + bh)) : 0u;
+  const unsigned kcol = (unsigned)(k0 + (lane & 31));
 
   TileStage<DH, 64> sq, sdo;
   float stat = 0.f;                                                   // threads 0..63: lse2, 64..127: delta
@@ -509,8 +531,15 @@ void attn_bwd_dkv_kernel(const AttnArgs a) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const float p = fast_exp2(s[4 * g + i] * c - l4[i]);
-            s[4 * g + i] = p;
-            ds[4 * g + i] = p * (dp[4 * g + i] - d4[i]);
+            float pd = p, dpv = dp[4 * g + i];
+            if (drop) {
+              const unsigned q = (unsigned)(j * 64 + 32 * qs + 8 * g + 4 * half + i);
+              const bool keep = mmf_keep(dkey, q * (unsigned)Tk + kcol, a.drop_thresh);
+              pd = keep ? p * a.inv_keep : 0.f;
+              dpv = keep ? dpv * a.inv_keep : 0.f;
+            }
+            s[4 * g + i] = pd;                            // dV^T += dO^T . P_dropped
+            ds[4 * g + i] = p * (dpv - d4[i]);
           }
         }
 #pragma unroll
@@ -563,8 +592,13 @@ int validate(const char* who, const mmf_attn_problem* p, int n, int head_dim, bo
   return MMF_OK;
 }
 
-int fill_args(AttnArgs& a, const mmf_attn_problem* p, int n, float scale, bool by_keys) {
+int fill_args(AttnArgs& a, const mmf_attn_problem* p, int n, float scale, bool by_keys, float drop_p,
+              const uint64_t* rng_state, uint32_t site) {
   a.nprob = n; a.scale = scale;
+  a.drop_thresh = (drop_p > 0.f && rng_state) ? mmf_drop_thresh(drop_p) : 0u;
+  a.inv_keep = a.drop_thresh ? 1.f / (1.f - (float)a.drop_thresh * (1.f / 4294967296.f)) : 1.f;
+  a.site = site;
+  a.rng_state = reinterpret_cast<const unsigned long long*>(rng_state);
   const char* dbg = getenv("MMF_ATTN_DEBUG");
   a.debug = dbg ? atoi(dbg) : 0;
   int total = 0;
@@ -580,30 +614,54 @@ int fill_args(AttnArgs& a, const mmf_attn_problem* p, int n, float scale, bool b
 
 }  // namespace
 
-extern "C" int mmf_attn_fwd_grouped(const mmf_attn_problem* problems, int num_problems, int head_dim,
-                                    float scale, void* stream) {
+extern "C" int mmf_attn_fwd_grouped_ex(const mmf_attn_problem* problems, int num_problems, int head_dim,
+                                       float scale, float dropout_p, const uint64_t* rng_state, uint32_t site,
+                                       void* stream) {
   if (int rc = validate("mmf_attn_fwd_grouped", problems, num_problems, head_dim, false)) return rc;
+  if (!(dropout_p >= 0.f) || dropout_p >= 1.f || (dropout_p > 0.f && !rng_state))
+    MMF_FAIL(MMF_E_SHAPE, "mmf_attn_fwd_grouped_ex: dropout needs 0 <= p < 1 and an rng_state");
   AttnArgs a;
-  const int total = fill_args(a, problems, num_problems, scale, false);
+  const int total = fill_args(a, problems, num_problems, scale, false, dropout_p, rng_state, site);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (head_dim == 96) hipLaunchKernelGGL(attn_fwd_kernel<96>, dim3(total), dim3(NT), 0, s, a);
-  else                hipLaunchKernelGGL(attn_fwd_kernel<64>, dim3(total), dim3(NT), 0, s, a);
+  const bool dr = a.drop_thresh != 0u;
+  if (head_dim == 96) { if (dr) hipLaunchKernelGGL((attn_fwd_kernel<96, true>), dim3(total), dim3(NT), 0, s, a);
+                        else    hipLaunchKernelGGL((attn_fwd_kernel<96, false>), dim3(total), dim3(NT), 0, s, a); }
+  else                { if (dr) hipLaunchKernelGGL((attn_fwd_kernel<64, true>), dim3(total), dim3(NT), 0, s, a);
+                        else    hipLaunchKernelGGL((attn_fwd_kernel<64, false>), dim3(total), dim3(NT), 0, s, a); }
   MMF_CHECK_LAUNCH("mmf_attn_fwd_grouped");
   return MMF_OK;
 }
 
-extern "C" int mmf_attn_bwd_grouped(const mmf_attn_problem* problems, int num_problems, int head_dim,
-                                    float scale, void* stream) {
+extern "C" int mmf_attn_bwd_grouped_ex(const mmf_attn_problem* problems, int num_problems, int head_dim,
+                                       float scale, float dropout_p, const uint64_t* rng_state, uint32_t site,
+                                       void* stream) {
   if (int rc = validate("mmf_attn_bwd_grouped", problems, num_problems, head_dim, true)) return rc;
+  if (!(dropout_p >= 0.f) || dropout_p >= 1.f || (dropout_p > 0.f && !rng_state))
+    MMF_FAIL(MMF_E_SHAPE, "mmf_attn_bwd_grouped_ex: dropout needs 0 <= p < 1 and an rng_state");
   hipStream_t s = static_cast<hipStream_t>(stream);
   AttnArgs a;
-  int total = fill_args(a, problems, num_problems, scale, false);          // dQ (+ delta) first
-  if (head_dim == 96) hipLaunchKernelGGL(attn_bwd_dq_kernel<96>, dim3(total), dim3(NT), 0, s, a);
-  else                hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, dim3(total), dim3(NT), 0, s, a);
+  int total = fill_args(a, problems, num_problems, scale, false, dropout_p, rng_state, site);   // dQ (+ delta) first
+  const bool dr = a.drop_thresh != 0u;
+  if (head_dim == 96) { if (dr) hipLaunchKernelGGL((attn_bwd_dq_kernel<96, true>), dim3(total), dim3(NT), 0, s, a);
+                        else    hipLaunchKernelGGL((attn_bwd_dq_kernel<96, false>), dim3(total), dim3(NT), 0, s, a); }
+  else                { if (dr) hipLaunchKernelGGL((attn_bwd_dq_kernel<64, true>), dim3(total), dim3(NT), 0, s, a);
+                        else    hipLaunchKernelGGL((attn_bwd_dq_kernel<64, false>), dim3(total), dim3(NT), 0, s, a); }
   MMF_CHECK_LAUNCH("mmf_attn_bwd_grouped(dq)");
-  total = fill_args(a, problems, num_problems, scale, true);               // then dK/dV (reads delta)
-  if (head_dim == 96) hipLaunchKernelGGL(attn_bwd_dkv_kernel<96>, dim3(total), dim3(NT), 0, s, a);
-  else                hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, dim3(total), dim3(NT), 0, s, a);
+  total = fill_args(a, problems, num_problems, scale, true, dropout_p, rng_state, site);        // then dK/dV (reads delta)
+  if (head_dim == 96) { if (dr) hipLaunchKernelGGL((attn_bwd_dkv_kernel<96, true>), dim3(total), dim3(NT), 0, s, a);
+                        else    hipLaunchKernelGGL((attn_bwd_dkv_kernel<96, false>), dim3(total), dim3(NT), 0, s, a); }
+  else                { if (dr) hipLaunchKernelGGL((attn_bwd_dkv_kernel<64, true>), dim3(total), dim3(NT), 0, s, a);
+                        else    hipLaunchKernelGGL((attn_bwd_dkv_kernel<64, false>), dim3(total), dim3(NT), 0, s, a); }
   MMF_CHECK_LAUNCH("mmf_attn_bwd_grouped(dkv)");
   return MMF_OK;
+}
+
+extern "C" int mmf_attn_fwd_grouped(const mmf_attn_problem* problems, int num_problems, int head_dim,
+                                    float scale, void* stream) {
+  return mmf_attn_fwd_grouped_ex(problems, num_problems, head_dim, scale, 0.f, nullptr, 0u, stream);
+}
+
+extern "C" int mmf_attn_bwd_grouped(const mmf_attn_problem* problems, int num_problems, int head_dim,
+                                    float scale, void* stream) {
+  return mmf_attn_bwd_grouped_ex(problems, num_problems, head_dim, scale, 0.f, nullptr, 0u, stream);
 }

@@ -112,6 +112,24 @@ void relu_bwd_kernel(const unsigned short* __restrict__ dy, const unsigned short
   }
 }
 
+template <typename T>
+__global__ __launch_bounds__(EW_THREADS)
+void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n, unsigned thresh, float scale,
+                    const unsigned long long* __restrict__ state, unsigned site) {
+  const unsigned key = mmf_rng_key(*state, site, 0u);
+  const int64_t stride = (int64_t)gridDim.x * EW_THREADS;
+  for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n; i += stride) {
+    const bool keep = mmf_keep(key ^ (unsigned)(i >> 32), (unsigned)i, thresh);
+    if (sizeof(T) == 4) {
+      const float v = reinterpret_cast<const float*>(x)[i];
+      reinterpret_cast<float*>(y)[i] = keep ? v * scale : 0.f;
+    } else {
+      const float v = bf16_bits_to_f32(reinterpret_cast<const unsigned short*>(x)[i]);
+      reinterpret_cast<unsigned short*>(y)[i] = keep ? f32_to_bf16_bits(v * scale) : (unsigned short)0;
+    }
+  }
+}
+
 // mean over T: grid (B, ceil(d/128)); a workgroup owns 128 columns of one sample: 16 lanes x 8 columns
 // (one 256-byte segment per row), 16 row groups walk T, LDS combine.  B * d/128 workgroups (96 for
 // B=16, d=768) instead of B * d/512.
@@ -235,6 +253,22 @@ extern "C" int mmf_add3_bf16(const void* a, const void* b, const void* c, void* 
                      static_cast<const unsigned short*>(a), static_cast<const unsigned short*>(b),
                      static_cast<const unsigned short*>(c), static_cast<unsigned short*>(y), n);
   MMF_CHECK_LAUNCH("mmf_add3_bf16");
+  return MMF_OK;
+}
+
+extern "C" int mmf_dropout(const void* x, void* y, int64_t n, int is_f32, float p, const uint64_t* rng_state,
+                           uint32_t site, void* stream) {
+  if (n <= 0) return MMF_OK;
+  if (!x || !y || !rng_state || !(p >= 0.f) || p >= 1.f) MMF_FAIL(MMF_E_SHAPE, "mmf_dropout: null pointer or p outside [0,1)");
+  const unsigned thresh = mmf_drop_thresh(p);
+  const float scale = 1.f / (1.f - (float)thresh * (1.f / 4294967296.f));
+  const unsigned long long* st = reinterpret_cast<const unsigned long long*>(rng_state);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (is_f32) hipLaunchKernelGGL(dropout_kernel<float>, dim3(ew_grid(n)), dim3(EW_THREADS), 0, s,
+                                 static_cast<const float*>(x), static_cast<float*>(y), n, thresh, scale, st, site);
+  else hipLaunchKernelGGL(dropout_kernel<unsigned short>, dim3(ew_grid(n)), dim3(EW_THREADS), 0, s,
+                          static_cast<const unsigned short*>(x), static_cast<unsigned short*>(y), n, thresh, scale, st, site);
+  MMF_CHECK_LAUNCH("mmf_dropout");
   return MMF_OK;
 }
 

@@ -242,7 +242,7 @@ int launch(const GemmArgs& a, int total_tiles, int out_f32, hipStream_t s) {
 }  // namespace
 
 int mmf_gemm2_launch(const mmf_gemm_problem* problems, int num_problems, int layout, int epilogue,
-                     int out_f32, hipStream_t s);      // gemm2.hip: LDS-DMA ring kernel
+                     int out_f32, const mmf_gemm_extra* extra, hipStream_t s);   // gemm2.hip: LDS-DMA ring kernel
 
 int mmf_gemm3_launch(const mmf_gemm_problem* problems, int num_problems, int layout, int epilogue,
                      int out_f32, hipStream_t s);      // gemm3.hip: persistent LDS-DMA ring kernel
@@ -263,6 +263,11 @@ extern "C" int mmf_gemm_select_impl(int impl) {
 
 extern "C" int mmf_gemm_grouped(const mmf_gemm_problem* problems, int num_problems, int layout,
                                 int epilogue, int out_f32, void* stream) {
+  return mmf_gemm_grouped_ex(problems, num_problems, layout, epilogue, out_f32, nullptr, stream);
+}
+
+extern "C" int mmf_gemm_grouped_ex(const mmf_gemm_problem* problems, int num_problems, int layout,
+                                   int epilogue, int out_f32, const mmf_gemm_extra* extra, void* stream) {
   if (!problems || num_problems <= 0 || num_problems > MMF_GEMM_MAX_PROBLEMS)
     MMF_FAIL(MMF_E_SHAPE, "mmf_gemm_grouped: num_problems=%d out of range [1,%d]", num_problems,
              MMF_GEMM_MAX_PROBLEMS);
@@ -274,7 +279,12 @@ extern "C" int mmf_gemm_grouped(const mmf_gemm_problem* problems, int num_proble
     MMF_FAIL(MMF_E_UNSUPPORTED, "mmf_gemm_grouped: MASK_AUX and ADD_AUX are exclusive");
   if ((epilogue & MMF_EPI_COLSUM_A) && (layout != MMF_GEMM_TN || (epilogue & MMF_EPI_BIAS)))
     MMF_FAIL(MMF_E_UNSUPPORTED, "mmf_gemm_grouped: COLSUM_A is a TN (wgrad) epilogue and excludes BIAS");
-  const int impl = gemm_impl();
+  const bool needs_v2 = extra && (extra->alpha != 1.f || (epilogue & MMF_EPI_DROPOUT));
+  if (epilogue & MMF_EPI_DROPOUT) {
+    if (!extra || !extra->rng_state || !(extra->dropout_p >= 0.f) || extra->dropout_p >= 1.f)
+      MMF_FAIL(MMF_E_SHAPE, "mmf_gemm_grouped_ex: MMF_EPI_DROPOUT needs rng_state and 0 <= p < 1");
+  }
+  const int impl = needs_v2 ? 2 : gemm_impl();     // only the gemm2 kernel has the alpha / dropout epilogue
   GemmArgs a;
   a.nprob = num_problems;
   a.epi = epilogue;
@@ -306,13 +316,13 @@ extern "C" int mmf_gemm_grouped(const mmf_gemm_problem* problems, int num_proble
   }
   a.tile_start[num_problems] = total;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (impl == 2) return mmf_gemm2_launch(problems, num_problems, layout, epilogue, out_f32, s);
+  if (impl == 2) return mmf_gemm2_launch(problems, num_problems, layout, epilogue, out_f32, extra, s);
   if (impl == 3) {
     bool wide_ok = true;              // the persistent kernel only has the 16-byte bf16 epilogue
     for (int i = 0; i < num_problems && !out_f32; ++i)
       wide_ok = wide_ok && !(problems[i].N & 7) && !(problems[i].ldc & 7);
     if (wide_ok) return mmf_gemm3_launch(problems, num_problems, layout, epilogue, out_f32, s);
-    return mmf_gemm2_launch(problems, num_problems, layout, epilogue, out_f32, s);
+    return mmf_gemm2_launch(problems, num_problems, layout, epilogue, out_f32, extra, s);
   }
   switch (layout) {
     case MMF_GEMM_NT: launch<false, false>(a, total, out_f32, s); break;

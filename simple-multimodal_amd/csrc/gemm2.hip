@@ -34,6 +34,9 @@ constexpr unsigned OOB = 0x80000000u;
 struct GemmArgs {
   int nprob;
   int epi;
+  float alpha;                       // multiplies the result after the mask step
+  unsigned drop_thresh, site;        // MMF_EPI_DROPOUT
+  const unsigned long long* rng_state;
   int tile_start[MMF_GEMM_MAX_PROBLEMS + 1];
   mmf_gemm_problem p[MMF_GEMM_MAX_PROBLEMS];
 };
@@ -236,11 +239,20 @@ void gemm2_grouped_kernel(const GemmArgs args, const int total_tiles) {
   // ---- epilogue: lane owns C[m][n..n+3] for each of its 16 MFMA tiles -------------------------------
   const int epi = args.epi;
   const unsigned short* __restrict__ aux = static_cast<const unsigned short*>(P.aux);
-  auto finish = [&](f32x4_t v, int m, int n) -> f32x4_t {          // bias -> relu -> mask -> residual
+  const bool do_drop = epi & MMF_EPI_DROPOUT;
+  const unsigned drop_key = do_drop ? mmf_rng_key(*args.rng_state, args.site, (unsigned)pi) : 0u;
+  const float drop_scale = do_drop ? 1.f / (1.f - (float)args.drop_thresh * (1.f / 4294967296.f)) : 1.f;
+  const float alpha = args.alpha;
+  auto finish = [&](f32x4_t v, int m, int n) -> f32x4_t {  // bias -> relu -> dropout -> mask -> alpha -> residual
     if (epi & MMF_EPI_BIAS) v += *reinterpret_cast<const f32x4_t*>(P.bias + n);
     if (epi & MMF_EPI_RELU) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+    }
+    if (do_drop) {
+      const unsigned idx = (unsigned)m * (unsigned)N + (unsigned)n;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = mmf_keep(drop_key, idx + e, args.drop_thresh) ? v[e] * drop_scale : 0.f;
     }
     if (epi & (MMF_EPI_MASK_AUX | MMF_EPI_ADD_AUX)) {
       const u32x2_t a = *reinterpret_cast<const u32x2_t*>(aux + (size_t)m * P.ldaux + n);
@@ -249,7 +261,10 @@ void gemm2_grouped_kernel(const GemmArgs args, const int total_tiles) {
         v[0] = a0 > 0.f ? v[0] : 0.f; v[1] = a1 > 0.f ? v[1] : 0.f;
         v[2] = a2 > 0.f ? v[2] : 0.f; v[3] = a3 > 0.f ? v[3] : 0.f;
       }
+      v *= alpha;
       if (epi & MMF_EPI_ADD_AUX) { v[0] += a0; v[1] += a1; v[2] += a2; v[3] += a3; }
+    } else {
+      v *= alpha;
     }
     return v;
   };
@@ -322,10 +337,14 @@ void launch(const GemmArgs& a, int total, int out_f32, hipStream_t s) {
 
 // called by mmf_gemm_grouped (gemm.hip) after validation
 int mmf_gemm2_launch(const mmf_gemm_problem* problems, int num_problems, int layout, int epilogue,
-                     int out_f32, hipStream_t s) {
+                     int out_f32, const mmf_gemm_extra* extra, hipStream_t s) {
   GemmArgs a;
   a.nprob = num_problems;
   a.epi = epilogue;
+  a.alpha = extra ? extra->alpha : 1.f;
+  a.drop_thresh = extra ? mmf_drop_thresh(extra->dropout_p) : 0u;
+  a.site = extra ? extra->site : 0u;
+  a.rng_state = extra ? reinterpret_cast<const unsigned long long*>(extra->rng_state) : nullptr;
   int total = 0;
   for (int i = 0; i < num_problems; ++i) {
     const mmf_gemm_problem& p = problems[i];

@@ -56,6 +56,27 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// ---- counter-based dropout RNG -----------------------------------------------------------------------
+// keep(e) for element e of dropout call-site `site`, stream `sub` (problem / (b,h) index) under the
+// DEVICE-resident 64-bit state `seed`: two rounds of the lowbias32 integer hash.  Stateless, so the
+// backward pass regenerates the forward's mask instead of storing it, and because the state lives in
+// device memory (advanced once per training step by the host side) a replayed hipGraph draws fresh
+// masks every step.  keep probability = 1 - p with p quantised to 2^-32.
+__device__ __forceinline__ unsigned mmf_mix32(unsigned x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ unsigned mmf_rng_key(unsigned long long seed, unsigned site, unsigned sub) {
+  return mmf_mix32((unsigned)seed ^ (site * 0x9E3779B9u)) ^ (unsigned)(seed >> 32) ^ (sub * 0x85EBCA6Bu);
+}
+__device__ __forceinline__ bool mmf_keep(unsigned key, unsigned idx, unsigned thresh) {
+  return mmf_mix32(key + idx * 0x9E3779B9u) >= thresh;
+}
+static inline unsigned mmf_drop_thresh(float p) {          // host: p in [0, 1)
+  double t = (double)p * 4294967296.0;
+  return t >= 4294967295.0 ? 4294967295u : (unsigned)t;
+}
+
 // transposed LDS read (ds_read_b64_tr_b16): per 16-lane group a 4-row x 16-column block of
 // 16-bit elements; lane 4q+p supplies the address of row q, columns 4p..4p+3; lane i receives
 // column i of the four rows (cdna_hip_programming.md T10).  EXEC must be all ones.

@@ -16,12 +16,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmmfusion.so")
 
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
-EPI_BIAS, EPI_RELU, EPI_MASK_AUX, EPI_ADD_AUX, EPI_ACCUM, EPI_COLSUM_A = 1, 2, 4, 8, 16, 32
+EPI_BIAS, EPI_RELU, EPI_MASK_AUX, EPI_ADD_AUX, EPI_ACCUM, EPI_COLSUM_A, EPI_DROPOUT = 1, 2, 4, 8, 16, 32, 64
 GEMM_MAX_PROBLEMS, ATTN_MAX_PROBLEMS, LN_MAX_PROBLEMS, COLSUM_MAX_PROBLEMS = 24, 12, 8, 24
 
 # every symbol include/mmfusion.h declares (tests check the .so exports all of them)
 SYMBOLS = (
-    "mmf_version", "mmf_last_error", "mmf_device_cu_count", "mmf_gemm_grouped", "mmf_gemm_select_impl",
+    "mmf_version", "mmf_last_error", "mmf_device_cu_count", "mmf_gemm_grouped", "mmf_gemm_grouped_ex", "mmf_gemm_select_impl",
+    "mmf_attn_fwd_grouped_ex", "mmf_attn_bwd_grouped_ex", "mmf_dropout",
     "mmf_attn_fwd_grouped", "mmf_attn_bwd_grouped", "mmf_layernorm_fwd_grouped",
     "mmf_layernorm_bwd_grouped", "mmf_layernorm_bwd_workspace_bytes", "mmf_cast_f32_to_bf16", "mmf_cast_bf16_to_f32", "mmf_add3_bf16",
     "mmf_meanpool_fwd", "mmf_meanpool_bwd", "mmf_colsum_bf16", "mmf_colsum_grouped", "mmf_relu_bwd_bf16",
@@ -49,6 +50,10 @@ class LnProblem(C.Structure):
                 ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("rows", C.c_int32)]
 
 
+class GemmExtra(C.Structure):
+    _fields_ = [("alpha", C.c_float), ("dropout_p", C.c_float), ("rng_state", C.c_void_p), ("site", C.c_uint32)]
+
+
 class ColsumProblem(C.Structure):
     _fields_ = [("x", C.c_void_p), ("out", C.c_void_p), ("M", C.c_int32), ("N", C.c_int32), ("ldx", C.c_int32)]
 
@@ -70,6 +75,10 @@ def load() -> C.CDLL:
     lib.mmf_version.restype = C.c_int
     vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
     lib.mmf_gemm_grouped.argtypes = [C.POINTER(GemmProblem), i32, i32, i32, i32, vp]
+    lib.mmf_gemm_grouped_ex.argtypes = [C.POINTER(GemmProblem), i32, i32, i32, i32, C.POINTER(GemmExtra), vp]
+    lib.mmf_attn_fwd_grouped_ex.argtypes = [C.POINTER(AttnProblem), i32, i32, f32, f32, vp, C.c_uint32, vp]
+    lib.mmf_attn_bwd_grouped_ex.argtypes = [C.POINTER(AttnProblem), i32, i32, f32, f32, vp, C.c_uint32, vp]
+    lib.mmf_dropout.argtypes = [vp, vp, i64, i32, f32, vp, C.c_uint32, vp]
     lib.mmf_attn_fwd_grouped.argtypes = [C.POINTER(AttnProblem), i32, i32, f32, vp]
     lib.mmf_attn_bwd_grouped.argtypes = [C.POINTER(AttnProblem), i32, i32, f32, vp]
     lib.mmf_layernorm_fwd_grouped.argtypes = [C.POINTER(LnProblem), i32, i32, f32, vp]
@@ -130,26 +139,35 @@ class _Timed:
             PROFILE.append((self.label, self.flops, self.e0, self.e1))
 
 
-def gemm_grouped(problems: Sequence[GemmProblem], layout: int, epilogue: int, out_f32: bool) -> None:
+def gemm_grouped(problems: Sequence[GemmProblem], layout: int, epilogue: int, out_f32: bool,
+                 alpha: float = 1.0, dropout_p: float = 0.0, rng_state_ptr: Optional[int] = None, site: int = 0) -> None:
     arr = (GemmProblem * len(problems))(*problems)
     flops = sum(2.0 * p.M * p.N * p.K for p in problems) if PROFILE is not None else 0.0
     with _Timed(f"gemm_grouped_kernel<{_LAYOUT_NAME[layout]},{'f32' if out_f32 else 'bf16'}>", flops):
-        check(load().mmf_gemm_grouped(arr, len(problems), layout, epilogue, int(out_f32), stream_ptr()))
+        if alpha == 1.0 and not (epilogue & EPI_DROPOUT):
+            check(load().mmf_gemm_grouped(arr, len(problems), layout, epilogue, int(out_f32), stream_ptr()))
+        else:
+            ex = GemmExtra(alpha, dropout_p, rng_state_ptr, site)
+            check(load().mmf_gemm_grouped_ex(arr, len(problems), layout, epilogue, int(out_f32), C.byref(ex), stream_ptr()))
 
 
-def attn_fwd_grouped(problems: Sequence[AttnProblem], head_dim: int, scale: float) -> None:
+def attn_fwd_grouped(problems: Sequence[AttnProblem], head_dim: int, scale: float, dropout_p: float = 0.0,
+                     rng_state_ptr: Optional[int] = None, site: int = 0) -> None:
     arr = (AttnProblem * len(problems))(*problems)
     flops = sum(4.0 * p.B * p.H * p.Tq * p.Tk * head_dim for p in problems) if PROFILE is not None else 0.0
     with _Timed(f"attn_fwd_kernel<{head_dim}>", flops):
-        check(load().mmf_attn_fwd_grouped(arr, len(problems), head_dim, scale, stream_ptr()))
+        check(load().mmf_attn_fwd_grouped_ex(arr, len(problems), head_dim, scale, dropout_p, rng_state_ptr, site,
+                                             stream_ptr()))
 
 
-def attn_bwd_grouped(problems: Sequence[AttnProblem], head_dim: int, scale: float) -> None:
+def attn_bwd_grouped(problems: Sequence[AttnProblem], head_dim: int, scale: float, dropout_p: float = 0.0,
+                     rng_state_ptr: Optional[int] = None, site: int = 0) -> None:
     arr = (AttnProblem * len(problems))(*problems)
     # algorithmic backward work: 4 products of 2*Tq*Tk*dh (dV, dP, dQ, dK); the recomputed S is not credited
     flops = sum(8.0 * p.B * p.H * p.Tq * p.Tk * head_dim for p in problems) if PROFILE is not None else 0.0
     with _Timed(f"attn_bwd_kernels<{head_dim}>", flops):
-        check(load().mmf_attn_bwd_grouped(arr, len(problems), head_dim, scale, stream_ptr()))
+        check(load().mmf_attn_bwd_grouped_ex(arr, len(problems), head_dim, scale, dropout_p, rng_state_ptr, site,
+                                             stream_ptr()))
 
 
 def layernorm_fwd_grouped(problems: Sequence[LnProblem], d: int, eps: float) -> None:

@@ -20,7 +20,7 @@ import torch
 
 from . import lib
 from .lib import (AttnProblem, GemmProblem, LnProblem, EPI_ACCUM, EPI_ADD_AUX, EPI_BIAS, EPI_COLSUM_A,
-                  EPI_MASK_AUX, EPI_RELU, GEMM_NN, GEMM_NT, GEMM_TN)
+                  EPI_DROPOUT, EPI_MASK_AUX, EPI_RELU, GEMM_NN, GEMM_NT, GEMM_TN)
 
 BF16 = torch.bfloat16
 
@@ -98,8 +98,10 @@ def gemm(layout: int, A: torch.Tensor, Bm: torch.Tensor, C: torch.Tensor, *, bia
     gemm_group(layout, [(A, Bm, C, bias, aux)], epilogue)
 
 
-def gemm_group(layout: int, probs: Sequence[tuple], epilogue: int) -> None:
-    """probs: (A, B, C, bias|None, aux|None) tensors; M,N from C; K from A."""
+def gemm_group(layout: int, probs: Sequence[tuple], epilogue: int, alpha: float = 1.0,
+               dropout: Optional[tuple] = None) -> None:
+    """probs: (A, B, C, bias|None, aux|None) tensors; M,N from C; K from A.
+    alpha scales the result after the mask step; dropout = (p, site) adds MMF_EPI_DROPOUT."""
     out_f32 = probs[0][2].dtype == torch.float32
     ps: List[GemmProblem] = []
     for (A, Bm, Cm, bias, aux) in probs:
@@ -124,8 +126,77 @@ def gemm_group(layout: int, probs: Sequence[tuple], epilogue: int) -> None:
                               bias.data_ptr() if bias is not None else None,
                               aux.data_ptr() if aux is not None else None,
                               M, N, K, _ld(A), _ld(Bm), _ld(Cm), _ld(aux) if aux is not None else 0))
+    if dropout is not None:
+        if len(ps) > lib.GEMM_MAX_PROBLEMS:
+            raise ValueError("a dropout GEMM group must fit one launch (the problem index keys the mask)")
+        lib.gemm_grouped(ps, layout, epilogue | EPI_DROPOUT, out_f32, alpha, dropout[0],
+                         rng_state().data_ptr(), dropout[1])
+        return
     for i in range(0, len(ps), lib.GEMM_MAX_PROBLEMS):
-        lib.gemm_grouped(ps[i:i + lib.GEMM_MAX_PROBLEMS], layout, epilogue, out_f32)
+        lib.gemm_grouped(ps[i:i + lib.GEMM_MAX_PROBLEMS], layout, epilogue, out_f32, alpha)
+
+
+# --------------------------------------------------------------------------------------------
+# dropout: device-resident RNG state + per-call-site ids
+# --------------------------------------------------------------------------------------------
+# Masks are a stateless hash of (state, site, element).  `state` is ONE int64 on the device: the root
+# forward of a training step adds 1 to it with a (graph-capturable) kernel, so every step — also every
+# replay of a captured step — draws new masks, and the backward pass regenerates the forward's masks
+# from the same (state, site).  `site` numbers the dropout call sites of one forward in call order.
+_rng_state: Optional[torch.Tensor] = None
+_site = 0
+
+
+def rng_state() -> torch.Tensor:
+    global _rng_state
+    if _rng_state is None:
+        _rng_state = torch.full((1,), (torch.initial_seed() & 0x7FFFFFFF) << 20, dtype=torch.int64, device="cuda")
+    return _rng_state
+
+
+def seed_dropout(seed: int) -> None:
+    rng_state().fill_((seed & 0x7FFFFFFF) << 20)
+
+
+def begin_training_forward() -> None:
+    """Called once per root forward in training mode: new masks, site numbering restarts."""
+    global _site
+    _site = 0
+    rng_state().add_(1)
+
+
+def next_site() -> int:
+    global _site
+    _site += 1
+    return _site
+
+
+class _Dropout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, site):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        lib.check(lib.load().mmf_dropout(x.data_ptr(), y.data_ptr(), x.numel(), int(x.dtype == torch.float32), p,
+                                         rng_state().data_ptr(), site, lib.stream_ptr()))
+        ctx.p, ctx.site = p, site
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        dx = torch.empty_like(g)
+        lib.check(lib.load().mmf_dropout(g.data_ptr(), dx.data_ptr(), g.numel(), int(g.dtype == torch.float32), ctx.p,
+                                         rng_state().data_ptr(), ctx.site, lib.stream_ptr()))
+        return dx, None, None
+
+
+def dropout(x: torch.Tensor, p: float, training: bool) -> torch.Tensor:
+    """nn.Dropout(p) on a bf16 or fp32 tensor (identity when not training or p == 0)."""
+    if not training or p <= 0.0:
+        return x
+    if x.dtype not in (BF16, torch.float32):
+        raise TypeError("dropout expects bf16 or fp32")
+    return _Dropout.apply(x, float(p), next_site())
 
 
 # --------------------------------------------------------------------------------------------
@@ -301,14 +372,16 @@ class _GroupedFFN(torch.autograd.Function):
     """tensors = [x_0, W1_0, b1_0, W2_0, b2_0, x_1, ...] (parameters passed so autograd runs backward)."""
 
     @staticmethod
-    def forward(ctx, layers, *tensors):
+    def forward(ctx, layers, drop, *tensors):
         n = len(layers)
         xs = [tensors[5 * i] for i in range(n)]
         for x in xs:
             _req(x, BF16)
         hs = [torch.empty((x.shape[0], l1.weight.shape[0]), dtype=BF16, device=x.device) for x, (l1, _) in zip(xs, layers)]
+        # h = dropout(relu(x W1^T + b1)) in one epilogue; dropped units are exactly 0 in h
         gemm_group(GEMM_NT, [(x, l1.weight._mmf_bf16, h, l1.bias.detach(), None)
-                             for x, h, (l1, _) in zip(xs, hs, layers)], EPI_BIAS | EPI_RELU)
+                             for x, h, (l1, _) in zip(xs, hs, layers)], EPI_BIAS | EPI_RELU, dropout=drop)
+        ctx.keep_scale = 1.0 / (1.0 - drop[0]) if drop is not None else 1.0
         ys = [torch.empty_like(x) for x in xs]
         gemm_group(GEMM_NT, [(h, l2.weight._mmf_bf16, y, l2.bias.detach(), x)
                              for x, h, y, (_, l2) in zip(xs, hs, ys, layers)], EPI_BIAS | EPI_ADD_AUX)
@@ -325,7 +398,9 @@ class _GroupedFFN(torch.autograd.Function):
         dys = {i: gys[i].contiguous() for i in idx}
         dhs = {i: torch.empty_like(hs[i]) for i in idx}
         dxs = {i: torch.empty_like(xs[i]) for i in idx}
-        gemm_group(GEMM_NN, [(dys[i], layers[i][1].weight._mmf_bf16, dhs[i], None, hs[i]) for i in idx], EPI_MASK_AUX)
+        # (h > 0) is ReLU mask AND dropout mask at once; only the 1/(1-p) factor is left to apply
+        gemm_group(GEMM_NN, [(dys[i], layers[i][1].weight._mmf_bf16, dhs[i], None, hs[i]) for i in idx], EPI_MASK_AUX,
+                   alpha=ctx.keep_scale)
         gemm_group(GEMM_NN, [(dhs[i], layers[i][0].weight._mmf_bf16, dxs[i], None, dys[i]) for i in idx], EPI_ADD_AUX)
         for i in idx:
             queue_wgrad(dys[i], hs[i], layers[i][1].weight.grad, layers[i][1].bias.grad)
@@ -333,11 +408,12 @@ class _GroupedFFN(torch.autograd.Function):
         grads: List[Optional[torch.Tensor]] = [None] * (5 * n)
         for i in idx:
             grads[5 * i] = dxs[i]
-        return (None, *grads)
+        return (None, None, *grads)
 
 
-def ffn_residual_group(items: Sequence[tuple]) -> List[torch.Tensor]:
-    """items: (x_bf16 [M, d], linear1 (d -> 4d), linear2 (4d -> d)); returns x + ffn(x) per item."""
+def ffn_residual_group(items: Sequence[tuple], dropout_p: float = 0.0) -> List[torch.Tensor]:
+    """items: (x_bf16 [M, d], linear1 (d -> 4d), linear2 (4d -> d)); returns x + ffn(x) per item.
+    dropout_p > 0: nn.Dropout on the hidden activations (reference :198), fused into the first GEMM."""
     layers, tensors = [], []
     for x, l1, l2 in items:
         for p in (l1.weight, l1.bias, l2.weight, l2.bias):
@@ -345,7 +421,8 @@ def ffn_residual_group(items: Sequence[tuple]) -> List[torch.Tensor]:
                 raise RuntimeError("FFN parameters are not arena-managed: call mmfusion.arena.ensure(module)")
         layers.append((l1, l2))
         tensors += [x, l1.weight, l1.bias, l2.weight, l2.bias]
-    return list(_GroupedFFN.apply(layers, *tensors))
+    drop = (float(dropout_p), next_site()) if dropout_p > 0.0 else None
+    return list(_GroupedFFN.apply(layers, drop, *tensors))
 
 
 # --------------------------------------------------------------------------------------------
@@ -431,7 +508,7 @@ class AttnSpec:
 
 class _GroupedAttention(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, specs: List[AttnSpec], H: int, dh: int, *srcs):
+    def forward(ctx, specs: List[AttnSpec], H: int, dh: int, drop, *srcs):
         scale = 1.0 / math.sqrt(dh)
         d = H * dh
         outs, lses, probs = [], [], []
@@ -449,9 +526,12 @@ class _GroupedAttention(torch.autograd.Function):
                                      o.data_ptr(), lse.data_ptr(), None, None, None, None, None,
                                      s.B, H, s.Tq, s.Tk, qs.shape[1], ks.shape[1], vs.shape[1], d))
             outs.append(o), lses.append(lse)
+        if drop is not None and len(probs) > lib.ATTN_MAX_PROBLEMS:
+            raise ValueError("an attention group with dropout must fit one launch (the problem index keys the mask)")
+        dp_, st_, site_ = (drop[0], rng_state().data_ptr(), drop[1]) if drop is not None else (0.0, None, 0)
         for i in range(0, len(probs), lib.ATTN_MAX_PROBLEMS):
-            lib.attn_fwd_grouped(probs[i:i + lib.ATTN_MAX_PROBLEMS], dh, scale)
-        ctx.specs, ctx.H, ctx.dh, ctx.nsrc = specs, H, dh, len(srcs)
+            lib.attn_fwd_grouped(probs[i:i + lib.ATTN_MAX_PROBLEMS], dh, scale, dp_, st_, site_)
+        ctx.specs, ctx.H, ctx.dh, ctx.nsrc, ctx.drop = specs, H, dh, len(srcs), drop
         ctx.save_for_backward(*srcs, *outs, *lses)
         return tuple(outs)
 
@@ -490,16 +570,22 @@ class _GroupedAttention(torch.autograd.Function):
                                      gsrc[s.q[0]].data_ptr() + 2 * s.q[1], gsrc[s.k[0]].data_ptr() + 2 * s.k[1],
                                      gsrc[s.v[0]].data_ptr() + 2 * s.v[1],
                                      s.B, H, s.Tq, s.Tk, qs.shape[1], ks.shape[1], vs.shape[1], d))
+        drop = ctx.drop
+        if drop is not None and len(probs) != len(specs):
+            raise RuntimeError("attention dropout backward needs the gradient of every problem of the group")
+        dp_, st_, site_ = (drop[0], rng_state().data_ptr(), drop[1]) if drop is not None else (0.0, None, 0)
         for i in range(0, len(probs), lib.ATTN_MAX_PROBLEMS):
-            lib.attn_bwd_grouped(probs[i:i + lib.ATTN_MAX_PROBLEMS], dh, 1.0 / math.sqrt(dh))
-        return (None, None, None, *gsrc)
+            lib.attn_bwd_grouped(probs[i:i + lib.ATTN_MAX_PROBLEMS], dh, 1.0 / math.sqrt(dh), dp_, st_, site_)
+        return (None, None, None, None, *gsrc)
 
 
-def attention_group(specs: List[AttnSpec], H: int, dh: int, srcs: Sequence[torch.Tensor]) -> List[torch.Tensor]:
+def attention_group(specs: List[AttnSpec], H: int, dh: int, srcs: Sequence[torch.Tensor],
+                    dropout_p: float = 0.0) -> List[torch.Tensor]:
     """Each (source, column) pair may be the k or v of several problems only if those problems'
     gradients are wanted separately — within one call every (source, column) range must be
     written by at most one problem's dK/dV (true for MulT: each block has its own K/V projection)."""
-    return list(_GroupedAttention.apply(specs, H, dh, *srcs))
+    drop = (float(dropout_p), next_site()) if dropout_p > 0.0 else None
+    return list(_GroupedAttention.apply(specs, H, dh, drop, *srcs))
 
 
 # --------------------------------------------------------------------------------------------

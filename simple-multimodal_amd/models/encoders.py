@@ -25,7 +25,7 @@ import torch.nn as nn
 
 from mmfusion import ops
 from mmfusion.ops import AttnSpec, W
-from .fusion_layers import _FusionBase, _MHAParams, _as_rows, _check_dropout, _wb
+from .fusion_layers import _FusionBase, _MHAParams, _as_rows, _p, _wb
 
 
 def _feature_mode(config) -> bool:
@@ -55,14 +55,13 @@ class AdapterLayer(_FusionBase):
         nn.init.zeros_(self.up_project.bias)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        _check_dropout(self, self.dropout.p)
         rows = _as_rows(x)
-        h = ops.linear(rows, *_wb(self.down_project), relu=True)
+        h = ops.dropout(ops.linear(rows, *_wb(self.down_project), relu=True), _p(self, self.dropout.p), True)
         y = ops.linear(h, *_wb(self.up_project), residual=rows)
         return ops.to_f32(y).reshape(x.shape)
 
 
-def _mha_mean_project(mha: _MHAParams, projection: nn.Linear, seq: torch.Tensor
+def _mha_mean_project(mha: _MHAParams, projection: nn.Linear, seq: torch.Tensor, p: float = 0.0
                       ) -> Tuple[torch.Tensor, torch.Tensor]:
     """self-MHA over T -> mean(T) -> Linear  (reference :152-160 / :236-244).
     Returns (projected (B, d_fusion) fp32, attended (B, T, hidden) fp32)."""
@@ -70,10 +69,11 @@ def _mha_mean_project(mha: _MHAParams, projection: nn.Linear, seq: torch.Tensor
     rows = _as_rows(seq)
     qkv = ops.linear(rows, mha.qkv_spec().w, mha.qkv_spec().b)
     att = ops.attention_group([AttnSpec(B, T, T, q=(0, 0), k=(0, hdim), v=(0, 2 * hdim))],
-                              mha.num_heads, mha.head_dim, [qkv])[0]
+                              mha.num_heads, mha.head_dim, [qkv], dropout_p=p)[0]
     attended = ops.linear(att, *_wb(mha.out_proj))
     pooled = ops.meanpool_cat([attended.view(B, T, hdim)])
-    return ops.linear(pooled, *_wb(projection), out_f32=True), ops.to_f32(attended).view(B, T, hdim)
+    projected = ops.dropout(ops.linear(pooled, *_wb(projection), out_f32=True), p, True)     # reference :161 / :245
+    return projected, ops.to_f32(attended).view(B, T, hdim)
 
 
 class TextEncoder(_FusionBase):
@@ -93,7 +93,6 @@ class TextEncoder(_FusionBase):
 
     def forward(self, input_ids, attention_mask, use_adapter: bool = False, use_prompt: bool = False
                 ) -> Dict[str, torch.Tensor]:
-        _check_dropout(self, self.config.fusion_dropout)
         cls_pool = True
         if self.model is None:                       # feature mode: input_ids holds (B, T, hidden)
             sequence_output = input_ids
@@ -116,7 +115,8 @@ class TextEncoder(_FusionBase):
         else:                                                              # reference :90-94
             m = attention_mask.unsqueeze(-1).to(sequence_output.dtype)
             pooled = (sequence_output * m).sum(1) / m.sum(1).clamp_min(1e-9)
-        projected = ops.linear(_as_rows(pooled), *_wb(self.projection), out_f32=True)
+        projected = ops.dropout(ops.linear(_as_rows(pooled), *_wb(self.projection), out_f32=True),
+                                _p(self, self.config.fusion_dropout), True)                  # reference :97-98
         return {"features": projected, "sequence_output": sequence_output, "attention_mask": attention_mask}
 
 
@@ -135,11 +135,11 @@ class AudioEncoder(_FusionBase):
         self.dropout = nn.Dropout(config.fusion_dropout)
 
     def forward(self, waveform, use_adapter: bool = False) -> Dict[str, torch.Tensor]:
-        _check_dropout(self, self.config.fusion_dropout)
         seq = waveform if self.model is None else self.model(waveform).last_hidden_state
         if use_adapter and self.adapter is not None:
             seq = self.adapter(seq)
-        projected, attended = _mha_mean_project(self.temporal_attention, self.projection, seq)
+        projected, attended = _mha_mean_project(self.temporal_attention, self.projection, seq,
+                                                _p(self, self.config.fusion_dropout))
         return {"features": projected, "sequence_output": attended, "attention_weights": None}
 
 
@@ -160,7 +160,6 @@ class VideoEncoder(_FusionBase):
         self.dropout = nn.Dropout(config.fusion_dropout)
 
     def forward(self, video_frames, use_adapter: bool = False) -> Dict[str, torch.Tensor]:
-        _check_dropout(self, self.config.fusion_dropout)
         if self.vit is None:                         # feature mode: (B, frames, hidden) CLS features
             frame_features = video_frames
         else:
@@ -170,7 +169,8 @@ class VideoEncoder(_FusionBase):
         if use_adapter and self.adapter is not None:
             frame_features = self.adapter(frame_features)
         lstm_out, _ = self.temporal_lstm(frame_features.float())
-        projected, attended = _mha_mean_project(self.facial_attention, self.projection, lstm_out)
+        projected, attended = _mha_mean_project(self.facial_attention, self.projection, lstm_out,
+                                                _p(self, self.config.fusion_dropout))
         return {"features": projected, "sequence_output": attended, "attention_weights": None}
 
 

@@ -12,7 +12,8 @@ hand-written gfx950 kernels of ``libmmfusion.so`` through ``mmfusion.ops``:
     per stage instead of six).
 
 There is no CPU path: calling these modules with CPU tensors raises.  Dropout (reference
-``fusion_dropout``) must be 0 or the module in eval mode for parity; see ``_check_dropout``.
+``fusion_dropout``) is applied in training mode at the reference's sites (attention probabilities, FFN
+hidden, fusion outputs) with the build's own counter-based RNG; parity runs use p = 0 or eval mode.
 """
 from __future__ import annotations
 
@@ -38,6 +39,8 @@ class _FusionBase(nn.Module):
         global _depth
         if _depth == 0:
             _arena.ensure(self, refresh=self.training)
+            if self.training:
+                ops.begin_training_forward()        # new dropout masks for this step
         _depth += 1
 
     @staticmethod
@@ -53,17 +56,12 @@ class _FusionBase(nn.Module):
             self._exit()
 
 
-_warned_dropout = False
-
-
-def _check_dropout(module: nn.Module, p: float) -> None:
-    """The reference applies dropout(p) to attention probabilities, FFN hidden and fusion outputs.
-    The HIP path has no in-kernel RNG yet: p > 0 in training mode is treated as identity, loudly."""
-    global _warned_dropout
-    if module.training and p > 0.0 and not _warned_dropout:
-        _warned_dropout = True
-        warnings.warn("mmfusion: fusion_dropout > 0 in training mode is not applied by the HIP path "
-                      "(treated as p = 0); set config.fusion_dropout = 0 for parity runs.")
+def _p(module: nn.Module, p: float) -> float:
+    """Effective dropout probability: nn.Dropout / nn.MultiheadAttention(dropout=p) act in training mode
+    only.  The HIP path draws its masks from a stateless hash of a device-resident step counter
+    (mmfusion.ops: dropout section), so masks differ from torch's Philox stream — same distribution,
+    checked statistically (tests/test_dropout_gpu.py); parity runs use p = 0 or eval()."""
+    return float(p) if (module.training and p > 0.0) else 0.0
 
 
 def _as_rows(x: torch.Tensor) -> torch.Tensor:
@@ -108,8 +106,8 @@ class _MHAParams(nn.Module):
 # grouped building blocks
 # ------------------------------------------------------------------------------------------------
 def _cross_blocks(blocks: Sequence["CrossModalTransformer"], qs: Sequence[torch.Tensor],
-                  kvs: Sequence[torch.Tensor], B: int, Tqs: Sequence[int], Tks: Sequence[int]
-                  ) -> List[torch.Tensor]:
+                  kvs: Sequence[torch.Tensor], B: int, Tqs: Sequence[int], Tks: Sequence[int],
+                  p: float = 0.0) -> List[torch.Tensor]:
     """n independent CrossModalTransformer blocks (reference :202-211), one launch per stage.
     qs[i]: bf16 (B*Tq_i, d); kvs[i]: bf16 (B*Tk_i, d)."""
     mp0 = blocks[0].attention
@@ -121,29 +119,29 @@ def _cross_blocks(blocks: Sequence["CrossModalTransformer"], qs: Sequence[torch.
     proj = ops.linear_group(items)                                   # [Q0, KV0, Q1, KV1, ...]
     specs = [AttnSpec(B, Tqs[i], Tks[i], q=(2 * i, 0), k=(2 * i + 1, 0), v=(2 * i + 1, d))
              for i in range(len(blocks))]
-    att = ops.attention_group(specs, H, dh, proj)
+    att = ops.attention_group(specs, H, dh, proj, dropout_p=p)              # dropout(p) on the probabilities
     pre1 = ops.linear_group([(att[i], _lin(blk.attention.out_proj), qs[i]) for i, blk in enumerate(blocks)])
     x = ops.layernorm_group([(pre1[i], blk.norm1.weight, blk.norm1.bias) for i, blk in enumerate(blocks)],
                             blocks[0].norm1.eps)
-    pre2 = ops.ffn_residual_group([(x[i], blk.ffn[0], blk.ffn[3]) for i, blk in enumerate(blocks)])
+    pre2 = ops.ffn_residual_group([(x[i], blk.ffn[0], blk.ffn[3]) for i, blk in enumerate(blocks)], dropout_p=p)
     return ops.layernorm_group([(pre2[i], blk.norm2.weight, blk.norm2.bias) for i, blk in enumerate(blocks)],
                                blocks[0].norm2.eps)
 
 
-def _self_attention_core(mhas: Sequence[_MHAParams], xs: Sequence[torch.Tensor], B: int, Ts: Sequence[int]
-                         ) -> List[torch.Tensor]:
+def _self_attention_core(mhas: Sequence[_MHAParams], xs: Sequence[torch.Tensor], B: int, Ts: Sequence[int],
+                         p: float = 0.0) -> List[torch.Tensor]:
     """packed QKV projection + fused attention of n independent self-attention MHAs; the
     out-projection is left to the caller."""
     d, H, dh = mhas[0].embed_dim, mhas[0].num_heads, mhas[0].head_dim
     qkv = ops.linear_group([(x, m.qkv_spec(), None) for m, x in zip(mhas, xs)])
     specs = [AttnSpec(B, Ts[i], Ts[i], q=(i, 0), k=(i, d), v=(i, 2 * d)) for i in range(len(mhas))]
-    return ops.attention_group(specs, H, dh, qkv)
+    return ops.attention_group(specs, H, dh, qkv, dropout_p=p)
 
 
-def _self_attention(mhas: Sequence[_MHAParams], xs: Sequence[torch.Tensor], B: int, Ts: Sequence[int]
-                    ) -> List[torch.Tensor]:
+def _self_attention(mhas: Sequence[_MHAParams], xs: Sequence[torch.Tensor], B: int, Ts: Sequence[int],
+                    p: float = 0.0) -> List[torch.Tensor]:
     """n independent self-attention MHAs without residual/LN (reference :161-163)."""
-    att = _self_attention_core(mhas, xs, B, Ts)
+    att = _self_attention_core(mhas, xs, B, Ts, p)
     return ops.linear_group([(att[i], _lin(m.out_proj), None) for i, m in enumerate(mhas)])
 
 
@@ -160,10 +158,10 @@ class EarlyFusion(_FusionBase):
             nn.Linear(2 * d, d), nn.ReLU(), nn.Dropout(config.fusion_dropout))
 
     def forward(self, text_features, audio_features, video_features) -> torch.Tensor:
-        _check_dropout(self, self.config.fusion_dropout)
+        p = _p(self, self.config.fusion_dropout)
         x = _as_rows(torch.cat([text_features, audio_features, video_features], dim=-1))
-        h = ops.linear(x, *_wb(self.fusion_layers[0]), relu=True)
-        return ops.linear(h, *_wb(self.fusion_layers[3]), relu=True, out_f32=True)
+        h = ops.dropout(ops.linear(x, *_wb(self.fusion_layers[0]), relu=True), p, True)
+        return ops.dropout(ops.linear(h, *_wb(self.fusion_layers[3]), relu=True, out_f32=True), p, True)
 
 
 def _wb(layer: nn.Linear):
@@ -208,10 +206,9 @@ class CrossModalTransformer(_FusionBase):
                                  nn.Linear(4 * d, d))
 
     def forward(self, query: torch.Tensor, key_value: torch.Tensor) -> torch.Tensor:
-        _check_dropout(self, self.dropout_p)
         B, Tq, d = query.shape
         Tk = key_value.shape[1]
-        y = _cross_blocks([self], [_as_rows(query)], [_as_rows(key_value)], B, [Tq], [Tk])[0]
+        y = _cross_blocks([self], [_as_rows(query)], [_as_rows(key_value)], B, [Tq], [Tk], _p(self, self.dropout_p))[0]
         return ops.to_f32(y).reshape(B, Tq, d)
 
 
@@ -235,7 +232,7 @@ class MultimodalTransformer(_FusionBase):
         self.final_fusion = nn.Sequential(nn.Linear(3 * d, d), nn.ReLU(), nn.Dropout(config.fusion_dropout))
 
     def forward(self, text_features, audio_features, video_features) -> Dict[str, torch.Tensor]:
-        _check_dropout(self, self.config.fusion_dropout)
+        p = _p(self, self.config.fusion_dropout)
         if text_features.dim() == 2:                                            # reference :140-143
             text_features, audio_features, video_features = (
                 text_features.unsqueeze(1), audio_features.unsqueeze(1), video_features.unsqueeze(1))
@@ -246,19 +243,19 @@ class MultimodalTransformer(_FusionBase):
                   self.video_to_text, self.video_to_audio]
         t_a, t_v, a_t, a_v, v_t, v_a = _cross_blocks(
             blocks, [t, t, a, a, v, v], [a, v, t, v, t, a], B, [Tt, Tt, Ta, Ta, Tv, Tv],
-            [Ta, Tv, Tt, Tv, Tt, Ta])                                           # :146-153
+            [Ta, Tv, Tt, Tv, Tt, Ta], p)                                        # :146-153
         et, ea, ev = ops.add3(t, t_a, t_v), ops.add3(a, a_t, a_v), ops.add3(v, v_t, v_a)   # :156-158
         # :161-168.  The self-attention outputs are only ever used through their mean over T, and the
         # out-projection is affine, so mean_t(out_proj(o_t)) == out_proj(mean_t o_t): pool the attention
         # output first and run the three out-projections on (B, d) instead of (B*T, d) rows — the same
         # arithmetic up to fp reassociation, minus 2*(Tt+Ta+Tv)*d^2 FLOP/sample forward and twice that backward.
         mhas = [self.text_self_attn, self.audio_self_attn, self.video_self_attn]
-        att = _self_attention_core(mhas, [et, ea, ev], B, [Tt, Ta, Tv])
+        att = _self_attention_core(mhas, [et, ea, ev], B, [Tt, Ta, Tv], p)
         pooled_att = ops.meanpool_cat([att[0].view(B, Tt, d), att[1].view(B, Ta, d), att[2].view(B, Tv, d)])
         proj = ops.linear_group([(pooled_att[:, i * d:(i + 1) * d], _lin(m.out_proj), None)
                                  for i, m in enumerate(mhas)])
         pooled = torch.cat(proj, dim=-1)                                        # :171  (B, 3d) bf16
-        fused = ops.linear(pooled, *_wb(self.final_fusion[0]), relu=True, out_f32=True)       # :172
+        fused = ops.dropout(ops.linear(pooled, *_wb(self.final_fusion[0]), relu=True, out_f32=True), p, True)  # :172
         pf = ops.to_f32(pooled)
         return {"fused_features": fused, "text_features": pf[:, :d], "audio_features": pf[:, d:2 * d],
                 "video_features": pf[:, 2 * d:]}
@@ -291,8 +288,8 @@ class _DenseGAT(nn.Module):
                 state_dict.setdefault(prefix + "lin.weight", w)
         super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
-    def forward(self, x: torch.Tensor, B: int) -> torch.Tensor:
-        """x: bf16 (B*3, in) -> fp32 (B, 3, out), ReLU not included."""
+    def forward(self, x: torch.Tensor, B: int, p: float = 0.0) -> torch.Tensor:
+        """x: bf16 (B*3, in) -> fp32 (B, 3, out), ReLU not included.  p: GATConv's dropout on alpha."""
         Hh, C = self.heads, self.out_channels
         h = ops.linear(x, W(self.lin.weight), None, out_f32=True).view(B, 3, Hh, C)   # MFMA GEMM
         # 3x3 additive attention per (sample, head): ~100 FLOP — torch glue
@@ -301,6 +298,8 @@ class _DenseGAT(nn.Module):
         e = F.leaky_relu(s_dst.unsqueeze(2) + s_src.unsqueeze(1), 0.2)                 # (B,i,j,H)
         ex = torch.exp(e - e.max(dim=2, keepdim=True).values)
         alpha = ex / (ex.sum(dim=2, keepdim=True) + 1e-16)
+        if p > 0.0:
+            alpha = F.dropout(alpha, p, True)           # (B,3,3,4) coefficients: torch RNG, plumbing-sized
         return torch.einsum("bijh,bjhc->bihc", alpha, h).mean(dim=2) + self.bias
 
 
@@ -321,8 +320,9 @@ class GraphFusion(_FusionBase):
         B = text_features.shape[0]
         x = torch.stack([text_features.float(), audio_features.float(), video_features.float()], dim=1)
         x = x + self.node_type_embedding.weight                                        # :255-264
+        pg = _p(self, self.config.graph_dropout)
         for layer in self.gcn_layers:                                                  # :280-282
-            x = torch.relu(layer(_as_rows(x), B))
+            x = torch.relu(layer(_as_rows(x), B, pg))
         pooled = x.mean(dim=1)                                                         # :285-286
         return ops.linear(_as_rows(pooled), *_wb(self.output_projection), out_f32=True)
 
@@ -342,7 +342,7 @@ class ContrastiveFusion(_FusionBase):
 
     def forward(self, text_features, audio_features, video_features,
                 compute_contrastive_loss: bool = False) -> Dict[str, torch.Tensor]:
-        _check_dropout(self, self.config.fusion_dropout)
+        p = _p(self, self.config.fusion_dropout)
         xs = [_as_rows(text_features), _as_rows(audio_features), _as_rows(video_features)]
         projs = [self.text_projector, self.audio_projector, self.video_projector]
         h = ops.linear_group([(x, _lin(p[0], relu=True), None) for x, p in zip(xs, projs)])
@@ -354,7 +354,7 @@ class ContrastiveFusion(_FusionBase):
                       "text_video": self.contrastive_loss(tp, vp),
                       "audio_video": self.contrastive_loss(ap, vp)}
         cat = _as_rows(torch.cat([text_features, audio_features, video_features], dim=-1))
-        fused = ops.linear(cat, *_wb(self.fusion_layer[0]), relu=True, out_f32=True)
+        fused = ops.dropout(ops.linear(cat, *_wb(self.fusion_layer[0]), relu=True, out_f32=True), p, True)
         return {"fused_features": fused, "text_proj": tp, "audio_proj": ap, "video_proj": vp,
                 "contrastive_losses": losses}
 
@@ -381,7 +381,7 @@ class AdaptiveFusion(_FusionBase):
         self.fusion_layer = nn.Sequential(nn.Linear(d, d), nn.ReLU(), nn.Dropout(config.fusion_dropout))
 
     def forward(self, text_features, audio_features, video_features) -> Dict[str, torch.Tensor]:
-        _check_dropout(self, self.config.fusion_dropout)
+        p = _p(self, self.config.fusion_dropout)
         B, d = text_features.shape
         mp = self.attention
         H, dh = mp.num_heads, mp.head_dim
@@ -390,7 +390,7 @@ class AdaptiveFusion(_FusionBase):
                                zip(xs, (self.text_transform, self.audio_transform, self.video_transform))])
         stacked = torch.stack(tr, dim=1).reshape(B * 3, d)                             # (B,3,d) :427-429
         qkv = ops.linear(stacked, mp.qkv_spec().w, mp.qkv_spec().b)
-        att = ops.attention_group([AttnSpec(B, 3, 3, q=(0, 0), k=(0, d), v=(0, 2 * d))], H, dh, [qkv])[0]
+        att = ops.attention_group([AttnSpec(B, 3, 3, q=(0, 0), k=(0, d), v=(0, 2 * d))], H, dh, [qkv], dropout_p=p)[0]
         attended = ops.linear(att, *_wb(mp.out_proj), out_f32=True).view(B, 3, d)
         with torch.no_grad():                      # head-averaged 3x3 weights, returned for inspection
             q4 = qkv.detach().float().view(B, 3, 3, H, dh)
@@ -400,7 +400,7 @@ class AdaptiveFusion(_FusionBase):
         hp = ops.linear(cat, *_wb(self.weight_predictor[0]), relu=True, out_f32=True)
         aw = F.softmax(F.linear(hp, self.weight_predictor[2].weight, self.weight_predictor[2].bias), dim=-1)
         weighted = (attended * aw.unsqueeze(-1)).sum(dim=1)                            # :441-443
-        fused = ops.linear(_as_rows(weighted), *_wb(self.fusion_layer[0]), relu=True, out_f32=True)
+        fused = ops.dropout(ops.linear(_as_rows(weighted), *_wb(self.fusion_layer[0]), relu=True, out_f32=True), p, True)
         return {"fused_features": fused, "attention_weights": attn_w, "adaptive_weights": aw}
 
 
@@ -427,7 +427,7 @@ class HierarchicalFusion(_FusionBase):
 
     def forward(self, text_features, audio_features, video_features,
                 compute_contrastive_loss: bool = False) -> Dict[str, torch.Tensor]:
-        _check_dropout(self, self.config.fusion_dropout)
+        p = _p(self, self.config.fusion_dropout)
         seq = (text_features, audio_features, video_features)
         if text_features.dim() == 3:
             d = text_features.shape[-1]
@@ -440,7 +440,7 @@ class HierarchicalFusion(_FusionBase):
         ada = self.adaptive_fusion(text_features, audio_features, video_features)
         allf = _as_rows(torch.cat([early, mult["fused_features"], graph, con["fused_features"],
                                    ada["fused_features"]], dim=-1))                    # :503-506
-        h = ops.linear(allf, *_wb(self.meta_fusion[0]), relu=True)
+        h = ops.dropout(ops.linear(allf, *_wb(self.meta_fusion[0]), relu=True), p, True)
         final = ops.linear(h, *_wb(self.meta_fusion[3]), out_f32=True)
         return {"fused_features": final, "early_features": early, "mult_features": mult["fused_features"],
                 "graph_features": graph, "contrastive_features": con["fused_features"],

@@ -44,7 +44,7 @@ def build_module(meta):
     else:
         m = getattr(fl, meta["cls"])(cfg)
     m.load_state_dict(fixture_params(meta), strict=True)      # reference state_dict keys/shapes
-    return m.cuda().train()                                   # dropout p = 0 in every fixture
+    return m.cuda().eval()      # as captured: eval mode (fixtures have p = 0; AdapterLayer's own 0.1 must be off)
 
 
 def run_hip(meta):
