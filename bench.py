@@ -49,15 +49,15 @@ def mult_flops_per_sample(Tt, Ta, Tv, d):
     return cross + selfa + 6 * d * d
 
 
-def build(workload, device, rank):
+def build(workload, device, rank, dropout=0.0):
     import config as cfgmod
     from mmfusion import synth
     from models import fusion_layers as fl
     from models.multimodal_model import EmotionClassifier
     S = synth.C2_SHAPES
     cfg = cfgmod.ModelConfig()
-    cfg.fusion_hidden_size, cfg.fusion_num_heads, cfg.fusion_dropout = S["d"], S["heads"], 0.0
-    cfg.graph_hidden_size, cfg.graph_num_layers, cfg.graph_dropout = S["d"], 3, 0.0
+    cfg.fusion_hidden_size, cfg.fusion_num_heads, cfg.fusion_dropout = S["d"], S["heads"], dropout
+    cfg.graph_hidden_size, cfg.graph_num_layers, cfg.graph_dropout = S["d"], 3, dropout
     torch.manual_seed(synth.WEIGHT_SEED)
     if workload == "train":
         class FusionWithHead(fl._FusionBase):          # one arena over fusion + classifier head
@@ -226,6 +226,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=5)
+    ap.add_argument("--dropout", type=float, default=0.0,
+                    help="fusion_dropout (headline = 0, the parity-comparable setting; 0.1 = reference default)")
     ap.add_argument("--allreduce", choices=["bf16", "fp32"], default="bf16",
                     help="wire dtype of the gradient all-reduce for N > 1 (compute and accumulation stay as is)")
     args = ap.parse_args()
@@ -247,7 +249,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from mmfusion import arena as arena_mod, dp, synth
-    cfg, model, xs = build(args.workload, device, rank)
+    cfg, model, xs = build(args.workload, device, rank, args.dropout)
     arena = arena_mod.ensure(model)
     use_graph = not args.no_graph
     graph = graph2 = None
@@ -344,7 +346,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": {"mult": "MulT fwd+bwd", "hier": "hier-seq fwd+bwd",
                                     "train": "hier-seq training step (fwd+bwd+clip+AdamW)"}[args.workload] +
-                                   ", B=16/GPU, T_text=512 T_audio=400 T_frames=30 d=768 H=8, fusion_dropout=0",
+                                   f", B=16/GPU, T_text=512 T_audio=400 T_frames=30 d=768 H=8, fusion_dropout={args.dropout:g}",
                        "global_batch": B * world, "parallelism": f"dp{world}",
                        "grad_allreduce": (args.allreduce if world > 1 else None),
                        "graph_replay": bool(use_graph)},

@@ -220,10 +220,32 @@ void gemm2_grouped_kernel(const GemmArgs args, const int total_tiles) {
     // fragments, then both issuing MFMAs.  Waves 0-3 prefetch before their MFMAs, waves 4-7 between
     // the two k-substeps, so one wave's DMA issue and fragment reads overlap its partner's MFMAs.
     const bool want_prefetch = kt + 2 < nk;
-    if (want_prefetch && wave < 4) issue_tile(kt + 2);
-    compute(0);
-    if (want_prefetch && wave >= 4) issue_tile(kt + 2);
-    compute(1);
+    if (!A_KR && !B_KR) {
+      // NT: both operands are plain ds_read_b128 (compiler-tracked), so all 16 fragment reads of the k-step
+      // are issued up front and the second k-substep's reads land under the first one's MFMAs.
+      if (want_prefetch && wave < 4) issue_tile(kt + 2);
+      bf16x8_t f0m[4], f0n[4], f1m[4], f1n[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { f0n[i] = read_frag_kc(sB, wn + i * 16, 0, lane); f0m[i] = read_frag_kc(sA, wm + i * 16, 0, lane); }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { f1n[i] = read_frag_kc(sB, wn + i * 16, 1, lane); f1m[i] = read_frag_kc(sA, wm + i * 16, 1, lane); }
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+          acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f0n[tn], f0m[tm], acc[tn][tm], 0, 0, 0);
+      if (want_prefetch && wave >= 4) issue_tile(kt + 2);
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+          acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f1n[tn], f1m[tm], acc[tn][tm], 0, 0, 0);
+    } else {
+      if (want_prefetch && wave < 4) issue_tile(kt + 2);
+      compute(0);
+      if (want_prefetch && wave >= 4) issue_tile(kt + 2);
+      compute(1);
+    }
   }
 
   if (A_KR && do_colsum) {              // every MFMA row holds the same sums: take row 0 (lanes 0..15, reg 0)
