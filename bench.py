@@ -89,7 +89,7 @@ def make_train_step(model, xs, arena, world, allreduce, rank):
     labels = torch.randint(0, 7, (xs[0].shape[0],), generator=g).to(xs[0].device)
 
     def fwd_bwd():
-        arena.zero_grad()
+        arena.zero_grad(overlap=True)
         out = model(*xs, compute_contrastive_loss=True)
         fusion_loss(out, labels).backward()
 
@@ -105,8 +105,9 @@ def make_train_step(model, xs, arena, world, allreduce, rank):
 def make_step(workload, model, xs, arena):
     def step():
         # the module's own entry hook re-casts the fp32 masters to the bf16 shadow on every training
-        # forward (what autocast does per forward), so the cast is inside the timed step
-        arena.zero_grad()
+        # forward (what autocast does per forward), so the cast is inside the timed step; the gradient
+        # arena is zeroed on the arena's side stream (joined inside the forward, before any backward kernel)
+        arena.zero_grad(overlap=True)
         if workload == "mult":
             out = model(*xs)
             loss = out["fused_features"].sum()

@@ -20,23 +20,38 @@ from __future__ import annotations
 
 from typing import Dict, List, Optional
 
+import os
+
 import torch
 
 from . import lib
 
 ALIGN = 64
+# Side-stream (fork/join) execution of the late shadow cast and of the gradient zeroing.  OFF by default:
+# measured on MI355X (same box, graph replay) it is a wash for MulT (3.09 vs 3.08-3.09 ms: the streams
+# compete with the in-projection GEMM for HBM) and a loss for the hierarchical training step (6.30 vs
+# 5.71 ms: multi-stream graph replay).  MMF_OVERLAP=1 enables it for A/B runs.
+OVERLAP = os.environ.get("MMF_OVERLAP", "0") == "1"
+
+
+def _is_early(name: str) -> bool:
+    """Parameters the first launches of a forward read: attention in-projections.  They are laid out at
+    the front of the arena so that their bf16 cast can run first while the rest streams on a side stream."""
+    return "in_proj" in name
 
 
 class ParamArena:
     def __init__(self, root: torch.nn.Module):
-        params: List[torch.nn.Parameter] = []
-        seen = set()
-        for p in root.parameters():
+        named, seen = [], set()
+        for n, p in root.named_parameters():
             if id(p) not in seen:
                 seen.add(id(p))
-                params.append(p)
-        if not params:
+                named.append((n, p))
+        if not named:
             raise ValueError("module has no parameters")
+        named.sort(key=lambda np_: 0 if _is_early(np_[0]) else 1)      # stable: early block first
+        params: List[torch.nn.Parameter] = [p for _, p in named]
+        n_early = sum(1 for n, _ in named if _is_early(n))
         dev = params[0].device
         if dev.type != "cuda":
             raise RuntimeError("mmfusion: the fusion path runs on the GPU only; move the module to a "
@@ -50,6 +65,9 @@ class ParamArena:
             self.offsets.append(off)
             off += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
         self.numel = off
+        self.early_numel = self.offsets[n_early] if n_early < len(params) else off
+        self._side: Optional[torch.cuda.Stream] = None      # fork/join stream for late cast + grad zeroing
+        self._pending = False
         self.master = torch.zeros(off, dtype=torch.float32, device=dev)
         self.shadow = torch.zeros(off, dtype=torch.bfloat16, device=dev)
         self.grads = torch.zeros(off, dtype=torch.float32, device=dev)
@@ -60,6 +78,7 @@ class ParamArena:
                 p.data = self.master[o:o + n].view(p.shape)
                 p._mmf_bf16 = self.shadow[o:o + n].view(p.shape)
                 p._mmf_arena = self
+                p._mmf_late = o >= self.early_numel
         self.attach_grads()
         self._cast_version = None
         self.refresh(force=True)
@@ -83,8 +102,32 @@ class ParamArena:
             for i, p in enumerate(self.params):
                 p.grad = self.grad_view(i)
 
-    def zero_grad(self) -> None:
-        self.grads.zero_()
+    def _fork(self) -> torch.cuda.Stream:
+        """Side stream that has waited for everything enqueued on the current stream so far."""
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.master.device)
+        if not self._pending:
+            self._side.wait_stream(torch.cuda.current_stream())
+            self._pending = True
+        return self._side
+
+    def join(self) -> None:
+        """Make the current stream wait for the side-stream work (late shadow cast, gradient zeroing).
+        Called by the ops before the first use of a late weight; a no-op when nothing is pending."""
+        if self._pending:
+            torch.cuda.current_stream().wait_stream(self._side)
+            self._pending = False
+
+    def zero_grad(self, overlap: bool = False) -> None:
+        """overlap=True enqueues the 4 B/param memset on the side stream; it is joined before the first
+        late weight is read in the NEXT forward, i.e. long before any backward kernel accumulates.  Only
+        for callers that run forward right after (bench.py, mmfusion.train)."""
+        if overlap and OVERLAP and self.grads.is_cuda:
+            with torch.cuda.stream(self._fork()):
+                self.grads.zero_()
+        else:
+            self.join()
+            self.grads.zero_()
 
     # -- bf16 shadow ---------------------------------------------------------------------------
     def _version(self) -> int:
@@ -107,8 +150,17 @@ class ParamArena:
             return                     # the fused optimiser keeps the shadow in step with the masters
         self._shadow_fresh = False
         if force or v != self._cast_version:
-            lib.check(lib.load().mmf_cast_f32_to_bf16(self.master.data_ptr(), self.shadow.data_ptr(),
-                                                      self.numel, lib.stream_ptr()))
+            L, e = lib.load(), self.early_numel
+            if OVERLAP and 0 < e < self.numel:
+                # late block (everything but the in-projections) on the side stream, in parallel with the
+                # first GEMMs / attention of the forward; early block on the current stream
+                with torch.cuda.stream(self._fork()):
+                    lib.check(L.mmf_cast_f32_to_bf16(self.master.data_ptr() + 4 * e, self.shadow.data_ptr() + 2 * e,
+                                                     self.numel - e, lib.stream_ptr()))
+                lib.check(L.mmf_cast_f32_to_bf16(self.master.data_ptr(), self.shadow.data_ptr(), e, lib.stream_ptr()))
+            else:
+                lib.check(L.mmf_cast_f32_to_bf16(self.master.data_ptr(), self.shadow.data_ptr(),
+                                                 self.numel, lib.stream_ptr()))
             self._cast_version = v
 
 

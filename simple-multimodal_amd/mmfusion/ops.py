@@ -40,11 +40,7 @@ class W:
 
     @property
     def w16(self) -> torch.Tensor:
-        s = getattr(self.p, "_mmf_bf16", None)
-        if s is None:
-            raise RuntimeError("parameter is not arena-managed: call mmfusion.arena.ensure(module) first")
-        a, b = self.rows()
-        return s[a:b]
+        return shadow(self.p)[self.rows()[0]:self.rows()[1]]
 
     @property
     def grad(self) -> torch.Tensor:
@@ -58,6 +54,17 @@ class W:
     def master(self) -> torch.Tensor:
         a, b = self.rows()
         return self.p.detach()[a:b]
+
+
+def shadow(p: torch.nn.Parameter) -> torch.Tensor:
+    """bf16 shadow of an arena-managed parameter.  Parameters outside the arena's early block are cast
+    on a side stream: reading one first joins that stream (mmfusion.arena.ParamArena.join)."""
+    s = getattr(p, "_mmf_bf16", None)
+    if s is None:
+        raise RuntimeError("parameter is not arena-managed: call mmfusion.arena.ensure(module) first")
+    if p._mmf_late:
+        p._mmf_arena.join()
+    return s
 
 
 def _ld(t: torch.Tensor) -> int:
@@ -379,11 +386,11 @@ class _GroupedFFN(torch.autograd.Function):
             _req(x, BF16)
         hs = [torch.empty((x.shape[0], l1.weight.shape[0]), dtype=BF16, device=x.device) for x, (l1, _) in zip(xs, layers)]
         # h = dropout(relu(x W1^T + b1)) in one epilogue; dropped units are exactly 0 in h
-        gemm_group(GEMM_NT, [(x, l1.weight._mmf_bf16, h, l1.bias.detach(), None)
+        gemm_group(GEMM_NT, [(x, shadow(l1.weight), h, l1.bias.detach(), None)
                              for x, h, (l1, _) in zip(xs, hs, layers)], EPI_BIAS | EPI_RELU, dropout=drop)
         ctx.keep_scale = 1.0 / (1.0 - drop[0]) if drop is not None else 1.0
         ys = [torch.empty_like(x) for x in xs]
-        gemm_group(GEMM_NT, [(h, l2.weight._mmf_bf16, y, l2.bias.detach(), x)
+        gemm_group(GEMM_NT, [(h, shadow(l2.weight), y, l2.bias.detach(), x)
                              for x, h, y, (_, l2) in zip(xs, hs, ys, layers)], EPI_BIAS | EPI_ADD_AUX)
         ctx.layers = layers
         ctx.save_for_backward(*xs, *hs)
@@ -399,9 +406,9 @@ class _GroupedFFN(torch.autograd.Function):
         dhs = {i: torch.empty_like(hs[i]) for i in idx}
         dxs = {i: torch.empty_like(xs[i]) for i in idx}
         # (h > 0) is ReLU mask AND dropout mask at once; only the 1/(1-p) factor is left to apply
-        gemm_group(GEMM_NN, [(dys[i], layers[i][1].weight._mmf_bf16, dhs[i], None, hs[i]) for i in idx], EPI_MASK_AUX,
+        gemm_group(GEMM_NN, [(dys[i], shadow(layers[i][1].weight), dhs[i], None, hs[i]) for i in idx], EPI_MASK_AUX,
                    alpha=ctx.keep_scale)
-        gemm_group(GEMM_NN, [(dhs[i], layers[i][0].weight._mmf_bf16, dxs[i], None, dys[i]) for i in idx], EPI_ADD_AUX)
+        gemm_group(GEMM_NN, [(dhs[i], shadow(layers[i][0].weight), dxs[i], None, dys[i]) for i in idx], EPI_ADD_AUX)
         for i in idx:
             queue_wgrad(dys[i], hs[i], layers[i][1].weight.grad, layers[i][1].bias.grad)
             queue_wgrad(dhs[i], xs[i], layers[i][0].weight.grad, layers[i][0].bias.grad)

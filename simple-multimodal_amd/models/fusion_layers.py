@@ -43,10 +43,13 @@ class _FusionBase(nn.Module):
                 ops.begin_training_forward()        # new dropout masks for this step
         _depth += 1
 
-    @staticmethod
-    def _exit():
+    def _exit(self):
         global _depth
         _depth -= 1
+        if _depth == 0:
+            arena = getattr(next(self.parameters(), None), "_mmf_arena", None)
+            if arena is not None:
+                arena.join()            # side-stream cast / zeroing never outlives the root forward
 
     def __call__(self, *args, **kwargs):
         self._enter()

@@ -62,8 +62,8 @@ def test_ffn_dropout_matches_reference_given_the_mask():
     # the same epilogue with and without dropout at site 1 -> the mask
     h0 = torch.empty((M, 4 * d), dtype=torch.bfloat16, device=DEV)
     h1 = torch.empty_like(h0)
-    ops.gemm_group(GEMM_NT, [(x, mod[0].weight._mmf_bf16, h0, mod[0].bias.detach(), None)], EPI_BIAS | EPI_RELU)
-    ops.gemm_group(GEMM_NT, [(x, mod[0].weight._mmf_bf16, h1, mod[0].bias.detach(), None)], EPI_BIAS | EPI_RELU,
+    ops.gemm_group(GEMM_NT, [(x, ops.shadow(mod[0].weight), h0, mod[0].bias.detach(), None)], EPI_BIAS | EPI_RELU)
+    ops.gemm_group(GEMM_NT, [(x, ops.shadow(mod[0].weight), h1, mod[0].bias.detach(), None)], EPI_BIAS | EPI_RELU,
                    dropout=(p, 1))
     mask = ((h1 != 0) | (h0 == 0)).float()
     kept = float(mask[h0 != 0].mean())
@@ -76,8 +76,8 @@ def test_ffn_dropout_matches_reference_given_the_mask():
     gy = rnd(M, d, seed=2).to(DEV).bfloat16()
     y.backward(gy)
     torch.cuda.synchronize()
-    W1, b1 = mod[0].weight._mmf_bf16.float().cpu().requires_grad_(True), mod[0].bias.detach().cpu().clone().requires_grad_(True)
-    W2, b2 = mod[1].weight._mmf_bf16.float().cpu().requires_grad_(True), mod[1].bias.detach().cpu().clone().requires_grad_(True)
+    W1, b1 = ops.shadow(mod[0].weight).float().cpu().requires_grad_(True), mod[0].bias.detach().cpu().clone().requires_grad_(True)
+    W2, b2 = ops.shadow(mod[1].weight).float().cpu().requires_grad_(True), mod[1].bias.detach().cpu().clone().requires_grad_(True)
     xr = x.float().cpu().requires_grad_(True)
     hr = torch.relu(xr @ W1.t() + b1) * mask.cpu() / (1 - p)
     yr = xr + hr.to(torch.bfloat16).float() @ W2.t() + b2

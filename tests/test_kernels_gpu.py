@@ -265,4 +265,4 @@ def test_fused_adamw_matches_torch():
         opt.step()
         for p, rp in zip(mod.parameters(), ref.parameters()):
             assert rel(p.detach(), rp.detach(), floor=1e-6) < 1e-5
-            assert rel(p._mmf_bf16, rp.detach().to(torch.bfloat16), floor=1e-6) < 2 ** -7
+            assert rel(ops.shadow(p), rp.detach().to(torch.bfloat16), floor=1e-6) < 2 ** -7
