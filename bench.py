@@ -229,6 +229,9 @@ def main():
     ap.add_argument("--profile-steps", type=int, default=5)
     ap.add_argument("--dropout", type=float, default=0.0,
                     help="fusion_dropout (headline = 0, the parity-comparable setting; 0.1 = reference default)")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only to rehearse the "
+                         "multi-rank code path on a box with fewer GPUs than ranks)")
     ap.add_argument("--allreduce", choices=["bf16", "fp32"], default="bf16",
                     help="wire dtype of the gradient all-reduce for N > 1 (compute and accumulation stay as is)")
     args = ap.parse_args()
@@ -241,13 +244,20 @@ def main():
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    if local_rank >= ndev and args.backend == "nccl":
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {ndev} GPU(s) visible")
+    dev_index = local_rank % max(ndev, 1)               # gloo rehearsal: ranks may share a GPU
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from mmfusion import arena as arena_mod, dp, synth
     cfg, model, xs = build(args.workload, device, rank, args.dropout)

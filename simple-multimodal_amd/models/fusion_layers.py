@@ -256,10 +256,10 @@ class MultimodalTransformer(_FusionBase):
         att = _self_attention_core(mhas, [et, ea, ev], B, [Tt, Ta, Tv], p)
         pooled_att = ops.meanpool_cat([att[0].view(B, Tt, d), att[1].view(B, Ta, d), att[2].view(B, Tv, d)])
         proj = ops.linear_group([(pooled_att[:, i * d:(i + 1) * d], _lin(m.out_proj), None)
-                                 for i, m in enumerate(mhas)])
-        pooled = torch.cat(proj, dim=-1)                                        # :171  (B, 3d) bf16
-        fused = ops.dropout(ops.linear(pooled, *_wb(self.final_fusion[0]), relu=True, out_f32=True), p, True)  # :172
-        pf = ops.to_f32(pooled)
+                                 for i, m in enumerate(mhas)], out_f32=True)    # (B, d) rows: f32 out is free
+        pf = torch.cat(proj, dim=-1)                                            # :171  (B, 3d) f32
+        fused = ops.dropout(ops.linear(ops.to_bf16(pf), *_wb(self.final_fusion[0]), relu=True, out_f32=True),
+                            p, True)                                            # :172
         return {"fused_features": fused, "text_features": pf[:, :d], "audio_features": pf[:, d:2 * d],
                 "video_features": pf[:, 2 * d:]}
 
