@@ -104,8 +104,8 @@ typedef struct mmf_gemm_extra {
 int mmf_gemm_grouped_ex(const mmf_gemm_problem* problems, int num_problems, int layout, int epilogue,
                         int out_f32, const mmf_gemm_extra* extra, void* stream);
 
-/* Tuning hook: which kernel generation mmf_gemm_grouped dispatches to (1 register-staged 128x128,
- * 2 LDS-DMA ring 256x128 [default], 3 persistent LDS-DMA ring).  Results are identical up to f32
+/* Tuning hook: which kernel generation mmf_gemm_grouped dispatches to (0 automatic [default], 1 register-staged 128x128,
+* 2 LDS-DMA ring 256x128, 3 persistent LDS-DMA ring, 4 LDS-DMA ring 256x256).  Results are identical up to f32
  * summation order; exists so that A/B timings can be interleaved inside one process. */
 int mmf_gemm_select_impl(int impl);
 

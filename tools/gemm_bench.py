@@ -67,7 +67,7 @@ def main():
                 us, tf = bench(layout, shapes, reps=10, epi=epi, f32=f32)
                 best[i] = max(best[i], tf)
         print(f"{name:24s} " + "  ".join(f"impl{i} {best[i]:7.1f} TF" for i in impls), flush=True)
-    lib.check(L.mmf_gemm_select_impl(2))
+    lib.check(L.mmf_gemm_select_impl(0))
 
 
 if __name__ == "__main__":
