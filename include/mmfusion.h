@@ -110,6 +110,30 @@ int mmf_gemm_grouped_ex(const mmf_gemm_problem* problems, int num_problems, int 
 int mmf_gemm_select_impl(int impl);
 
 /* ------------------------------------------------------------------------------------------
+ * Skinny-M linear layers (1 <= M <= 64 rows): the (B, d) MLPs of the Early / Contrastive / Adaptive /
+ * Graph / meta branches (models/fusion_layers.py:21-28, 304-327, 395-412, 471-476) and MulT's pooled
+ * projections.  Weight-streaming MFMA kernels with the weight tile on the MFMA row axis; the grouped GEMM
+ * above would spend >90 % of a 256-row tile on padding.
+ *   fwd:   Y[m][n] = act(sum_k X[m][k] W[n][k] + bias[n])           flags: MMF_EPI_BIAS | MMF_EPI_RELU
+ *   dgrad: Y[m][k] = (sum_n X[m][n] W[n][k]) * (aux[m][k] > 0) * alpha   flags: MMF_EPI_MASK_AUX
+ *          (X = dy [M][N], W [N][K], Y = dx [M][K]; N = W rows = reduction, K = W columns)
+ * X, W, aux bf16; Y bf16 or f32; wgrad goes through mmf_gemm_grouped (TN).
+ * ------------------------------------------------------------------------------------------ */
+#define MMF_SKINNY_MAX_PROBLEMS 24
+typedef struct mmf_skinny_problem {
+  const void* X;      /* bf16 [M][ldx] */
+  const void* W;      /* bf16 [N][ldw] */
+  void* Y;            /* bf16 or f32 */
+  const float* bias;  /* f32 [N] (fwd) or NULL */
+  const void* aux;    /* bf16 [M][ldaux] (dgrad mask) or NULL */
+  int32_t M, N, K;    /* W is N x K */
+  int32_t ldx, ldw, ldy, ldaux;
+} mmf_skinny_problem;
+int mmf_skinny_linear_fwd(const mmf_skinny_problem* problems, int num_problems, int flags, int out_f32, void* stream);
+int mmf_skinny_linear_dgrad(const mmf_skinny_problem* problems, int num_problems, int flags, float alpha, int out_f32,
+                            void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Grouped fused attention (flash-style: no (Tq,Tk) score matrix in HBM).
  * Replaces q*scale, QK^T, softmax, P.V of F.multi_head_attention_forward as called at
  * models/fusion_layers.py:161-163,204 (six cross blocks + three self blocks of MulT in ONE

@@ -1,0 +1,240 @@
+// Skinny-M linear layers (M <= 64 rows: the (B, d) branches of the hierarchical fusion — Early, Contrastive,
+// Adaptive, Graph, meta MLPs, reference models/fusion_layers.py:21-28,304-327,395-412,471-476 — and the
+// pooled projections of MulT).  These are weight-streaming problems: 2 bytes of W per M*2 FLOP, so the
+// 256-row GEMM tile wastes >90 % of its work on them.  Here the WEIGHT tile rides the MFMA row axis
+// (v_mfma_f32_16x16x32_bf16, D[i = n or k_in][j = m]) and all of M (1..4 column tiles of 16) is the other
+// operand; a workgroup owns one strip of output columns, its 4 waves split the reduction and combine in LDS.
+//
+//   forward  y[m][n]   = act(sum_k x[m][k] W[n][k] + b[n])        W rows are k-contiguous: fragments straight
+//                                                                 from HBM/L2, no LDS staging at all;
+//   dgrad    dx[m][k]  = (sum_n dy[m][n] W[n][k]) * (aux>0) * alpha   the reduction index is W's ROW: each wave
+//                                                                 stages 32 x 64 blocks of W in a private LDS
+//                                                                 slice and reads them back transposed
+//                                                                 (ds_read_b64_tr_b16).
+// wgrad (dW = dy^T x, output-bound) stays on the grouped TN kernel via the deferred launch.
+#include "mmf_internal.h"
+
+namespace {
+
+constexpr int SK_THREADS = 256;
+constexpr int MAX_MT = 4;                  // up to 64 rows
+
+struct SkinnyArgs {
+  int nprob;
+  int flags;                               // MMF_EPI_BIAS | MMF_EPI_RELU | MMF_EPI_MASK_AUX
+  float alpha;
+  int blk_start[MMF_SKINNY_MAX_PROBLEMS + 1];
+  mmf_skinny_problem p[MMF_SKINNY_MAX_PROBLEMS];
+};
+
+__device__ __forceinline__ bf16x8_t load_frag_rows(const unsigned short* __restrict__ base, int ld, int row, int rows,
+                                                   int col, int cols) {
+  u32x4_t v = {0u, 0u, 0u, 0u};
+  if (row < rows && col < cols) v = *reinterpret_cast<const u32x4_t*>(base + (size_t)row * ld + col);
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+
+// ---- forward ---------------------------------------------------------------------------------------------
+template <bool OUT_F32>
+__global__ __launch_bounds__(SK_THREADS)
+void skinny_fwd_kernel(const SkinnyArgs a) {
+  __shared__ __attribute__((aligned(16))) float red[3][MAX_MT][64][4];
+  int pi = 0;
+  while (pi + 1 < a.nprob && (int)blockIdx.x >= a.blk_start[pi + 1]) ++pi;
+  const mmf_skinny_problem& P = a.p[pi];
+  const int M = P.M, N = P.N, K = P.K;
+  const int n0 = ((int)blockIdx.x - a.blk_start[pi]) * 16;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int mt = (M + 15) >> 4;
+  const unsigned short* __restrict__ X = static_cast<const unsigned short*>(P.X);
+  const unsigned short* __restrict__ W = static_cast<const unsigned short*>(P.W);
+
+  // this wave's quarter of K, in whole 32-element MFMA steps
+  const int steps = (K + 31) >> 5, per = (steps + 3) >> 2;
+  const int s0 = wave * per, s1 = min(steps, s0 + per);
+  f32x4_t acc[MAX_MT];
+#pragma unroll
+  for (int t = 0; t < MAX_MT; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int wrow = n0 + (lane & 15), kc = (lane >> 4) << 3;
+  for (int s = s0; s < s1; ++s) {
+    const int k = (s << 5) + kc;
+    const bf16x8_t wf = load_frag_rows(W, P.ldw, wrow, N, k, K);
+#pragma unroll
+    for (int t = 0; t < MAX_MT; ++t) {
+      if (t < mt) {
+        const bf16x8_t xf = load_frag_rows(X, P.ldx, t * 16 + (lane & 15), M, k, K);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, acc[t], 0, 0, 0);
+      }
+    }
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int t = 0; t < MAX_MT; ++t)
+      if (t < mt) *reinterpret_cast<f32x4_t*>(&red[wave - 1][t][lane][0]) = acc[t];
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const int n = n0 + ((lane >> 4) << 2);             // D[i = n][j = m]: lane holds n..n+3 of row m
+#pragma unroll
+    for (int t = 0; t < MAX_MT; ++t) {
+      const int m = t * 16 + (lane & 15);
+      if (t < mt && m < M && n < N) {
+        f32x4_t v = acc[t];
+#pragma unroll
+        for (int w = 0; w < 3; ++w) v += *reinterpret_cast<const f32x4_t*>(&red[w][t][lane][0]);
+        if (a.flags & MMF_EPI_BIAS) v += *reinterpret_cast<const f32x4_t*>(P.bias + n);
+        if (a.flags & MMF_EPI_RELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (OUT_F32) {
+          *reinterpret_cast<f32x4_t*>(static_cast<float*>(P.Y) + (size_t)m * P.ldy + n) = v;
+        } else {
+          const u32x2_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+          *reinterpret_cast<u32x2_t*>(static_cast<unsigned short*>(P.Y) + (size_t)m * P.ldy + n) = o;
+        }
+      }
+    }
+  }
+}
+
+// ---- dgrad -----------------------------------------------------------------------------------------------
+// X := dy [M][N_out] (bf16), W [N_out][K_in], Y := dx [M][K_in]; aux (bf16 [M][K_in], optional) is the saved
+// activation whose sign gates the gradient (ReLU / dropout mask), alpha the 1/(1-p) of a dropout backward.
+template <bool OUT_F32>
+__global__ __launch_bounds__(SK_THREADS)
+void skinny_dgrad_kernel(const SkinnyArgs a) {
+  constexpr int SB = (64 + 8) * 2;                                       // padded slice row: 64 k_in + 8
+  __shared__ __attribute__((aligned(16))) char smem[4 * 32 * SB > (int)sizeof(float) * 3 * 4 * MAX_MT * 64 * 4
+                                                    ? 4 * 32 * SB : (int)sizeof(float) * 3 * 4 * MAX_MT * 64 * 4];
+  int pi = 0;
+  while (pi + 1 < a.nprob && (int)blockIdx.x >= a.blk_start[pi + 1]) ++pi;
+  const mmf_skinny_problem& P = a.p[pi];
+  const int M = P.M, Nout = P.N, Kin = P.K;
+  const int c0 = ((int)blockIdx.x - a.blk_start[pi]) * 64;              // first k_in column of this strip
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int mt = (M + 15) >> 4;
+  const unsigned short* __restrict__ dY = static_cast<const unsigned short*>(P.X);
+  const unsigned short* __restrict__ W = static_cast<const unsigned short*>(P.W);
+  char* slice = smem + wave * 32 * SB;
+
+  const int steps = (Nout + 31) >> 5, per = (steps + 3) >> 2;
+  const int s0 = wave * per, s1 = min(steps, s0 + per);
+  f32x4_t acc[4][MAX_MT];                                                // [k_in tile][m tile]
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int t = 0; t < MAX_MT; ++t) acc[c][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+  for (int s = s0; s < s1; ++s) {
+    const int r0 = s << 5;                                               // 32 rows of W (reduction index n_out)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                                        // 32 x 64 block, 16-B chunks, coalesced
+      const int ch = lane + 64 * i, row = ch >> 3, col = (ch & 7) << 3;
+      u32x4_t v = {0u, 0u, 0u, 0u};
+      if (r0 + row < Nout && c0 + col < Kin) v = *reinterpret_cast<const u32x4_t*>(W + (size_t)(r0 + row) * P.ldw + c0 + col);
+      *reinterpret_cast<u32x4_t*>(slice + row * SB + col * 2) = v;
+    }
+    bf16x8_t yf[MAX_MT];
+#pragma unroll
+    for (int t = 0; t < MAX_MT; ++t)
+      if (t < mt) yf[t] = load_frag_rows(dY, P.ldx, t * 16 + (lane & 15), M, r0 + (g << 3), Nout);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      // W^T fragment: lane (i = k_in column c*16 + (l & 15), k = n_out 8g + e) from rows 8g .. 8g+7 of the slice
+      const char* ap = slice + (8 * g + q) * SB + (c * 16 + 4 * pp) * 2;
+      const s16x4_t lo = lds_read_tr16(ap);
+      const s16x4_t hi = lds_read_tr16(ap + 4 * SB);
+      const s16x8_t wv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      const bf16x8_t wf = __builtin_bit_cast(bf16x8_t, wv);
+#pragma unroll
+      for (int t = 0; t < MAX_MT; ++t)
+        if (t < mt) acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, yf[t], acc[c][t], 0, 0, 0);
+    }
+  }
+  __syncthreads();                                                       // slices are dead: reuse LDS for the sums
+  float* red = reinterpret_cast<float*>(smem);                           // [3 waves][4 c][MAX_MT][64 lanes][4]
+  if (wave > 0) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int t = 0; t < MAX_MT; ++t)
+        if (t < mt) *reinterpret_cast<f32x4_t*>(red + ((((wave - 1) * 4 + c) * MAX_MT + t) * 64 + lane) * 4) = acc[c][t];
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const unsigned short* __restrict__ aux = static_cast<const unsigned short*>(P.aux);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int k = c0 + c * 16 + (g << 2);                              // D[i = k_in][j = m]
+#pragma unroll
+      for (int t = 0; t < MAX_MT; ++t) {
+        const int m = t * 16 + (lane & 15);
+        if (t < mt && m < M && k < Kin) {
+          f32x4_t v = acc[c][t];
+#pragma unroll
+          for (int w = 0; w < 3; ++w) v += *reinterpret_cast<const f32x4_t*>(red + (((w * 4 + c) * MAX_MT + t) * 64 + lane) * 4);
+          if (a.flags & MMF_EPI_MASK_AUX) {
+            const u32x2_t x = *reinterpret_cast<const u32x2_t*>(aux + (size_t)m * P.ldaux + k);
+            v[0] = bf16lo(x[0]) > 0.f ? v[0] : 0.f; v[1] = bf16hi(x[0]) > 0.f ? v[1] : 0.f;
+            v[2] = bf16lo(x[1]) > 0.f ? v[2] : 0.f; v[3] = bf16hi(x[1]) > 0.f ? v[3] : 0.f;
+          }
+          v *= a.alpha;
+          if (OUT_F32) {
+            *reinterpret_cast<f32x4_t*>(static_cast<float*>(P.Y) + (size_t)m * P.ldy + k) = v;
+          } else {
+            const u32x2_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            *reinterpret_cast<u32x2_t*>(static_cast<unsigned short*>(P.Y) + (size_t)m * P.ldy + k) = o;
+          }
+        }
+      }
+    }
+  }
+}
+
+int check(const char* who, const mmf_skinny_problem* p, int n, int flags, bool dgrad) {
+  if (!p || n <= 0 || n > MMF_SKINNY_MAX_PROBLEMS) MMF_FAIL(MMF_E_SHAPE, "%s: num_problems=%d out of range", who, n);
+  for (int i = 0; i < n; ++i) {
+    const mmf_skinny_problem& q = p[i];
+    if (q.M <= 0 || q.M > 16 * MAX_MT || q.N <= 0 || q.K <= 0)
+      MMF_FAIL(MMF_E_SHAPE, "%s[%d]: M=%d (1..%d) N=%d K=%d", who, i, q.M, 16 * MAX_MT, q.N, q.K);
+    const int out_cols = dgrad ? q.K : q.N, red = dgrad ? q.N : q.K;
+    if ((red & 7) || (q.ldx & 7) || (q.ldw & 7) || (out_cols & 3) || (q.ldy & 3) || (dgrad && (q.K & 7)))
+      MMF_FAIL(MMF_E_ALIGN, "%s[%d]: reduction extent / leading dimensions must be multiples of 8, outputs of 4", who, i);
+    if (!q.X || !q.W || !q.Y || !mmf_aligned16(q.X) || !mmf_aligned16(q.W) || !mmf_aligned16(q.Y))
+      MMF_FAIL(MMF_E_ALIGN, "%s[%d]: null or unaligned operand", who, i);
+    if ((flags & MMF_EPI_BIAS) && (!q.bias || !mmf_aligned16(q.bias))) MMF_FAIL(MMF_E_SHAPE, "%s[%d]: bias", who, i);
+    if ((flags & MMF_EPI_MASK_AUX) && (!q.aux || (q.ldaux & 3))) MMF_FAIL(MMF_E_SHAPE, "%s[%d]: aux", who, i);
+  }
+  return MMF_OK;
+}
+
+}  // namespace
+
+extern "C" int mmf_skinny_linear_fwd(const mmf_skinny_problem* problems, int num_problems, int flags, int out_f32,
+                                     void* stream) {
+  if (int rc = check("mmf_skinny_linear_fwd", problems, num_problems, flags, false)) return rc;
+  SkinnyArgs a; a.nprob = num_problems; a.flags = flags; a.alpha = 1.f;
+  int total = 0;
+  for (int i = 0; i < num_problems; ++i) { a.blk_start[i] = total; total += (problems[i].N + 15) / 16; a.p[i] = problems[i]; }
+  a.blk_start[num_problems] = total;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (out_f32) hipLaunchKernelGGL(skinny_fwd_kernel<true>, dim3(total), dim3(SK_THREADS), 0, s, a);
+  else         hipLaunchKernelGGL(skinny_fwd_kernel<false>, dim3(total), dim3(SK_THREADS), 0, s, a);
+  MMF_CHECK_LAUNCH("mmf_skinny_linear_fwd");
+  return MMF_OK;
+}
+
+extern "C" int mmf_skinny_linear_dgrad(const mmf_skinny_problem* problems, int num_problems, int flags, float alpha,
+                                       int out_f32, void* stream) {
+  if (int rc = check("mmf_skinny_linear_dgrad", problems, num_problems, flags, true)) return rc;
+  SkinnyArgs a; a.nprob = num_problems; a.flags = flags; a.alpha = alpha;
+  int total = 0;
+  for (int i = 0; i < num_problems; ++i) { a.blk_start[i] = total; total += (problems[i].K + 63) / 64; a.p[i] = problems[i]; }
+  a.blk_start[num_problems] = total;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (out_f32) hipLaunchKernelGGL(skinny_dgrad_kernel<true>, dim3(total), dim3(SK_THREADS), 0, s, a);
+  else         hipLaunchKernelGGL(skinny_dgrad_kernel<false>, dim3(total), dim3(SK_THREADS), 0, s, a);
+  MMF_CHECK_LAUNCH("mmf_skinny_linear_dgrad");
+  return MMF_OK;
+}

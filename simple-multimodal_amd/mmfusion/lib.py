@@ -26,7 +26,7 @@ SYMBOLS = (
     "mmf_attn_fwd_grouped", "mmf_attn_bwd_grouped", "mmf_layernorm_fwd_grouped",
     "mmf_layernorm_bwd_grouped", "mmf_layernorm_bwd_workspace_bytes", "mmf_cast_f32_to_bf16", "mmf_cast_bf16_to_f32", "mmf_add3_bf16",
     "mmf_meanpool_fwd", "mmf_meanpool_bwd", "mmf_colsum_bf16", "mmf_colsum_grouped", "mmf_relu_bwd_bf16",
-    "mmf_sqnorm_f32", "mmf_adamw_step",
+    "mmf_sqnorm_f32", "mmf_adamw_step", "mmf_skinny_linear_fwd", "mmf_skinny_linear_dgrad",
 )
 
 
@@ -52,6 +52,15 @@ class LnProblem(C.Structure):
 
 class GemmExtra(C.Structure):
     _fields_ = [("alpha", C.c_float), ("dropout_p", C.c_float), ("rng_state", C.c_void_p), ("site", C.c_uint32)]
+
+
+class SkinnyProblem(C.Structure):
+    _fields_ = [("X", C.c_void_p), ("W", C.c_void_p), ("Y", C.c_void_p), ("bias", C.c_void_p), ("aux", C.c_void_p),
+                ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("ldx", C.c_int32), ("ldw", C.c_int32),
+                ("ldy", C.c_int32), ("ldaux", C.c_int32)]
+
+
+SKINNY_MAX_M, SKINNY_MAX_PROBLEMS = 64, 24
 
 
 class ColsumProblem(C.Structure):
@@ -93,6 +102,8 @@ def load() -> C.CDLL:
     lib.mmf_colsum_bf16.argtypes = [vp, vp, i32, i32, i32, vp]
     lib.mmf_colsum_grouped.argtypes = [C.POINTER(ColsumProblem), i32, vp]
     lib.mmf_relu_bwd_bf16.argtypes = [vp, vp, vp, i64, vp]
+    lib.mmf_skinny_linear_fwd.argtypes = [C.POINTER(SkinnyProblem), i32, i32, i32, vp]
+    lib.mmf_skinny_linear_dgrad.argtypes = [C.POINTER(SkinnyProblem), i32, i32, f32, i32, vp]
     lib.mmf_sqnorm_f32.argtypes = [vp, i64, vp, vp]
     lib.mmf_adamw_step.argtypes = [vp, vp, vp, vp, vp, i64, vp, vp, vp]
     for name in SYMBOLS:
@@ -187,3 +198,17 @@ def colsum_grouped(problems: Sequence[ColsumProblem]) -> None:
         chunk = problems[i:i + COLSUM_MAX_PROBLEMS]
         arr = (ColsumProblem * len(chunk))(*chunk)
         check(load().mmf_colsum_grouped(arr, len(chunk), stream_ptr()))
+
+
+def skinny_fwd(problems: Sequence[SkinnyProblem], flags: int, out_f32: bool) -> None:
+    for i in range(0, len(problems), SKINNY_MAX_PROBLEMS):
+        chunk = problems[i:i + SKINNY_MAX_PROBLEMS]
+        arr = (SkinnyProblem * len(chunk))(*chunk)
+        check(load().mmf_skinny_linear_fwd(arr, len(chunk), flags, int(out_f32), stream_ptr()))
+
+
+def skinny_dgrad(problems: Sequence[SkinnyProblem], flags: int, alpha: float, out_f32: bool) -> None:
+    for i in range(0, len(problems), SKINNY_MAX_PROBLEMS):
+        chunk = problems[i:i + SKINNY_MAX_PROBLEMS]
+        arr = (SkinnyProblem * len(chunk))(*chunk)
+        check(load().mmf_skinny_linear_dgrad(arr, len(chunk), flags, alpha, int(out_f32), stream_ptr()))

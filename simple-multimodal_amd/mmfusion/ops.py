@@ -216,6 +216,7 @@ def dropout(x: torch.Tensor, p: float, training: bool) -> torch.Tensor:
 import os as _os
 
 DEFER_WGRAD = _os.environ.get("MMF_DEFER_WGRAD", "1") != "0"
+_SKINNY = _os.environ.get("MMF_SKINNY", "1") != "0"          # skinny-M kernels for problems with <= 64 rows
 _pending_wgrad: List[tuple] = []
 
 
@@ -304,7 +305,14 @@ class _GroupedLinear(torch.autograd.Function):
             probs.append((x, w16, y, bias, res))
             xs.append(x), ress.append(res), outs.append(y)
         epi = (EPI_BIAS if has_bias else 0) | (EPI_RELU if relu else 0) | (EPI_ADD_AUX if has_res else 0)
-        gemm_group(GEMM_NT, probs, epi)
+        skinny = _SKINNY and not has_res and all(x.shape[0] <= lib.SKINNY_MAX_M and x.shape[1] % 8 == 0 for x in xs)
+        if skinny:          # (B, d)-row problems: weight-streaming kernels instead of the 256-row tile
+            lib.skinny_fwd([lib.SkinnyProblem(x.data_ptr(), w.data_ptr(), y.data_ptr(),
+                                              b.data_ptr() if b is not None else None, None,
+                                              x.shape[0], w.shape[0], x.shape[1], _ld(x), _ld(w), _ld(y), 0)
+                            for (x, w, y, b, _) in probs], epi, out_f32)
+        else:
+            gemm_group(GEMM_NT, probs, epi)
         ctx.specs, ctx.out_f32 = specs, out_f32
         ctx.save_for_backward(*xs, *(outs if relu else []))
         ctx.x_needs = [tensors[4 * i].requires_grad for i in range(n)]
@@ -349,7 +357,12 @@ class _GroupedLinear(torch.autograd.Function):
             if s.has_residual:
                 grads[4 * i + 1] = g
         if dgrad:
-            gemm_group(GEMM_NN, dgrad, 0)
+            if _SKINNY and all(g.shape[0] <= lib.SKINNY_MAX_M for (g, _, _, _, _) in dgrad):
+                lib.skinny_dgrad([lib.SkinnyProblem(g.data_ptr(), w.data_ptr(), dx.data_ptr(), None, None,
+                                                    g.shape[0], w.shape[0], w.shape[1], _ld(g), _ld(w), _ld(dx), 0)
+                                  for (g, w, dx, _, _) in dgrad], 0, 1.0, False)
+            else:
+                gemm_group(GEMM_NN, dgrad, 0)
         return (None, None, *grads)
 
 

@@ -266,3 +266,41 @@ def test_fused_adamw_matches_torch():
         for p, rp in zip(mod.parameters(), ref.parameters()):
             assert rel(p.detach(), rp.detach(), floor=1e-6) < 1e-5
             assert rel(ops.shadow(p), rp.detach().to(torch.bfloat16), floor=1e-6) < 2 ** -7
+
+
+# ---------------------------------------------------------------------------------------- skinny-M linear
+@pytest.mark.parametrize("M,N,K", [(16, 768, 2304), (4, 256, 768), (48, 3072, 768), (64, 384, 768), (1, 8, 8),
+                                   (16, 1536, 3840), (3, 72, 40)])
+def test_skinny_fwd_and_dgrad(M, N, K):
+    x, w, b = bf(rnd(M, K, seed=1)), bf(rnd(N, K, seed=2, scale=K ** -0.5)), rnd(N, seed=3).to(DEV)
+    ref = x.float().cpu() @ w.float().cpu().t() + b.cpu()
+    y = torch.full((M, N), float("nan"), device=DEV)
+    p = lib.SkinnyProblem(x.data_ptr(), w.data_ptr(), y.data_ptr(), b.data_ptr(), None, M, N, K, K, K, N, 0)
+    lib.skinny_fwd([p], EPI_BIAS, True)
+    assert rel(y, ref) < 1e-5
+    y16 = torch.empty((M, N), dtype=torch.bfloat16, device=DEV)
+    p = lib.SkinnyProblem(x.data_ptr(), w.data_ptr(), y16.data_ptr(), b.data_ptr(), None, M, N, K, K, K, N, 0)
+    lib.skinny_fwd([p], EPI_BIAS | EPI_RELU, False)
+    assert rel(y16, torch.relu(ref)) < 2 ** -8
+    # dgrad: dx = (dy W) * (aux > 0) * alpha
+    dy, aux = bf(rnd(M, N, seed=4)), bf(rnd(M, K, seed=5))
+    dref = dy.float().cpu() @ w.float().cpu()
+    dx = torch.full((M, K), float("nan"), device=DEV)
+    p = lib.SkinnyProblem(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), None, None, M, N, K, N, K, K, 0)
+    lib.skinny_dgrad([p], 0, 1.0, True)
+    assert rel(dx, dref) < 1e-5
+    dx16 = torch.empty((M, K), dtype=torch.bfloat16, device=DEV)
+    p = lib.SkinnyProblem(dy.data_ptr(), w.data_ptr(), dx16.data_ptr(), None, aux.data_ptr(), M, N, K, N, K, K, K)
+    lib.skinny_dgrad([p], EPI_MASK_AUX, 2.0, False)
+    assert rel(dx16, dref * (aux.float().cpu() > 0) * 2.0) < 2 ** -8
+
+
+def test_skinny_grouped_strided():
+    big = bf(rnd(16, 2304, seed=9))
+    ws = [bf(rnd(768, 768, seed=10 + i, scale=0.05)) for i in range(3)]
+    ys = [torch.empty((16, 768), dtype=torch.bfloat16, device=DEV) for _ in range(3)]
+    probs = [lib.SkinnyProblem(big.data_ptr() + 2 * 768 * i, ws[i].data_ptr(), ys[i].data_ptr(), None, None,
+                               16, 768, 768, 2304, 768, 768, 0) for i in range(3)]
+    lib.skinny_fwd(probs, 0, False)
+    for i in range(3):
+        assert rel(ys[i], big[:, 768 * i:768 * (i + 1)].float().cpu() @ ws[i].float().cpu().t()) < 2 ** -8
