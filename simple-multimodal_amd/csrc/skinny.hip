@@ -16,7 +16,8 @@
 
 namespace {
 
-constexpr int SK_THREADS = 256;
+constexpr int SK_THREADS = 512;               // 8 waves split the reduction
+constexpr int SK_WAVES = SK_THREADS / 64;
 constexpr int MAX_MT = 4;                  // up to 64 rows
 
 struct SkinnyArgs {
@@ -38,7 +39,7 @@ __device__ __forceinline__ bf16x8_t load_frag_rows(const unsigned short* __restr
 template <bool OUT_F32>
 __global__ __launch_bounds__(SK_THREADS)
 void skinny_fwd_kernel(const SkinnyArgs a) {
-  __shared__ __attribute__((aligned(16))) float red[3][MAX_MT][64][4];
+  __shared__ __attribute__((aligned(16))) float red[SK_WAVES - 1][MAX_MT][64][4];
   int pi = 0;
   while (pi + 1 < a.nprob && (int)blockIdx.x >= a.blk_start[pi + 1]) ++pi;
   const mmf_skinny_problem& P = a.p[pi];
@@ -49,23 +50,31 @@ void skinny_fwd_kernel(const SkinnyArgs a) {
   const unsigned short* __restrict__ X = static_cast<const unsigned short*>(P.X);
   const unsigned short* __restrict__ W = static_cast<const unsigned short*>(P.W);
 
-  // this wave's quarter of K, in whole 32-element MFMA steps
-  const int steps = (K + 31) >> 5, per = (steps + 3) >> 2;
+  // this wave's share of K, in whole 32-element MFMA steps; the next step's fragments are requested
+  // before the current step's MFMAs (the chain is otherwise one HBM/L2 latency per step)
+  const int steps = (K + 31) >> 5, per = (steps + SK_WAVES - 1) / SK_WAVES;
   const int s0 = wave * per, s1 = min(steps, s0 + per);
   f32x4_t acc[MAX_MT];
 #pragma unroll
   for (int t = 0; t < MAX_MT; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   const int wrow = n0 + (lane & 15), kc = (lane >> 4) << 3;
-  for (int s = s0; s < s1; ++s) {
+  bf16x8_t wf, xf[MAX_MT], wn_, xn_[MAX_MT];
+  auto fetch = [&](int s, bf16x8_t& w, bf16x8_t (&x)[MAX_MT]) {
     const int k = (s << 5) + kc;
-    const bf16x8_t wf = load_frag_rows(W, P.ldw, wrow, N, k, K);
+    w = load_frag_rows(W, P.ldw, wrow, N, k, K);
 #pragma unroll
-    for (int t = 0; t < MAX_MT; ++t) {
-      if (t < mt) {
-        const bf16x8_t xf = load_frag_rows(X, P.ldx, t * 16 + (lane & 15), M, k, K);
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, acc[t], 0, 0, 0);
-      }
-    }
+    for (int t = 0; t < MAX_MT; ++t)
+      if (t < mt) x[t] = load_frag_rows(X, P.ldx, t * 16 + (lane & 15), M, k, K);
+  };
+  if (s0 < s1) fetch(s0, wf, xf);
+  for (int s = s0; s < s1; ++s) {
+    if (s + 1 < s1) fetch(s + 1, wn_, xn_);
+#pragma unroll
+    for (int t = 0; t < MAX_MT; ++t)
+      if (t < mt) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[t], acc[t], 0, 0, 0);
+    wf = wn_;
+#pragma unroll
+    for (int t = 0; t < MAX_MT; ++t) xf[t] = xn_[t];
   }
   if (wave > 0) {
 #pragma unroll
@@ -81,7 +90,7 @@ void skinny_fwd_kernel(const SkinnyArgs a) {
       if (t < mt && m < M && n < N) {
         f32x4_t v = acc[t];
 #pragma unroll
-        for (int w = 0; w < 3; ++w) v += *reinterpret_cast<const f32x4_t*>(&red[w][t][lane][0]);
+        for (int w = 0; w < SK_WAVES - 1; ++w) v += *reinterpret_cast<const f32x4_t*>(&red[w][t][lane][0]);
         if (a.flags & MMF_EPI_BIAS) v += *reinterpret_cast<const f32x4_t*>(P.bias + n);
         if (a.flags & MMF_EPI_RELU) {
 #pragma unroll
@@ -105,8 +114,9 @@ template <bool OUT_F32>
 __global__ __launch_bounds__(SK_THREADS)
 void skinny_dgrad_kernel(const SkinnyArgs a) {
   constexpr int SB = (64 + 8) * 2;                                       // padded slice row: 64 k_in + 8
-  __shared__ __attribute__((aligned(16))) char smem[4 * 32 * SB > (int)sizeof(float) * 3 * 4 * MAX_MT * 64 * 4
-                                                    ? 4 * 32 * SB : (int)sizeof(float) * 3 * 4 * MAX_MT * 64 * 4];
+  constexpr int RED_BYTES = (int)sizeof(float) * (SK_WAVES - 1) * 4 * MAX_MT * 64 * 4;     // 112 KiB
+  constexpr int SLICE_BYTES = SK_WAVES * 32 * SB;
+  __shared__ __attribute__((aligned(16))) char smem[SLICE_BYTES > RED_BYTES ? SLICE_BYTES : RED_BYTES];
   int pi = 0;
   while (pi + 1 < a.nprob && (int)blockIdx.x >= a.blk_start[pi + 1]) ++pi;
   const mmf_skinny_problem& P = a.p[pi];
@@ -118,7 +128,7 @@ void skinny_dgrad_kernel(const SkinnyArgs a) {
   const unsigned short* __restrict__ W = static_cast<const unsigned short*>(P.W);
   char* slice = smem + wave * 32 * SB;
 
-  const int steps = (Nout + 31) >> 5, per = (steps + 3) >> 2;
+  const int steps = (Nout + 31) >> 5, per = (steps + SK_WAVES - 1) / SK_WAVES;
   const int s0 = wave * per, s1 = min(steps, s0 + per);
   f32x4_t acc[4][MAX_MT];                                                // [k_in tile][m tile]
 #pragma unroll
@@ -126,19 +136,29 @@ void skinny_dgrad_kernel(const SkinnyArgs a) {
 #pragma unroll
     for (int t = 0; t < MAX_MT; ++t) acc[c][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
-  for (int s = s0; s < s1; ++s) {
-    const int r0 = s << 5;                                               // 32 rows of W (reduction index n_out)
+  u32x4_t stage[4];
+  bf16x8_t yf[MAX_MT], yn_[MAX_MT];
+  auto fetch = [&](int s, bf16x8_t (&y)[MAX_MT]) {                       // 32 x 64 block of W (16-B chunks, coalesced) + dy
+    const int r0 = s << 5;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {                                        // 32 x 64 block, 16-B chunks, coalesced
+    for (int i = 0; i < 4; ++i) {
       const int ch = lane + 64 * i, row = ch >> 3, col = (ch & 7) << 3;
       u32x4_t v = {0u, 0u, 0u, 0u};
       if (r0 + row < Nout && c0 + col < Kin) v = *reinterpret_cast<const u32x4_t*>(W + (size_t)(r0 + row) * P.ldw + c0 + col);
-      *reinterpret_cast<u32x4_t*>(slice + row * SB + col * 2) = v;
+      stage[i] = v;
     }
-    bf16x8_t yf[MAX_MT];
 #pragma unroll
     for (int t = 0; t < MAX_MT; ++t)
-      if (t < mt) yf[t] = load_frag_rows(dY, P.ldx, t * 16 + (lane & 15), M, r0 + (g << 3), Nout);
+      if (t < mt) y[t] = load_frag_rows(dY, P.ldx, t * 16 + (lane & 15), M, r0 + (g << 3), Nout);
+  };
+  if (s0 < s1) fetch(s0, yf);
+  for (int s = s0; s < s1; ++s) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int ch = lane + 64 * i, row = ch >> 3, col = (ch & 7) << 3;
+      *reinterpret_cast<u32x4_t*>(slice + row * SB + col * 2) = stage[i];
+    }
+    if (s + 1 < s1) fetch(s + 1, yn_);                                   // next block in flight under the MFMAs
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       // W^T fragment: lane (i = k_in column c*16 + (l & 15), k = n_out 8g + e) from rows 8g .. 8g+7 of the slice
@@ -151,9 +171,11 @@ void skinny_dgrad_kernel(const SkinnyArgs a) {
       for (int t = 0; t < MAX_MT; ++t)
         if (t < mt) acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, yf[t], acc[c][t], 0, 0, 0);
     }
+#pragma unroll
+    for (int t = 0; t < MAX_MT; ++t) yf[t] = yn_[t];
   }
   __syncthreads();                                                       // slices are dead: reuse LDS for the sums
-  float* red = reinterpret_cast<float*>(smem);                           // [3 waves][4 c][MAX_MT][64 lanes][4]
+  float* red = reinterpret_cast<float*>(smem);                           // [7 waves][4 c][MAX_MT][64 lanes][4]
   if (wave > 0) {
 #pragma unroll
     for (int c = 0; c < 4; ++c)
@@ -173,7 +195,7 @@ void skinny_dgrad_kernel(const SkinnyArgs a) {
         if (t < mt && m < M && k < Kin) {
           f32x4_t v = acc[c][t];
 #pragma unroll
-          for (int w = 0; w < 3; ++w) v += *reinterpret_cast<const f32x4_t*>(red + (((w * 4 + c) * MAX_MT + t) * 64 + lane) * 4);
+          for (int w = 0; w < SK_WAVES - 1; ++w) v += *reinterpret_cast<const f32x4_t*>(red + (((w * 4 + c) * MAX_MT + t) * 64 + lane) * 4);
           if (a.flags & MMF_EPI_MASK_AUX) {
             const u32x2_t x = *reinterpret_cast<const u32x2_t*>(aux + (size_t)m * P.ldaux + k);
             v[0] = bf16lo(x[0]) > 0.f ? v[0] : 0.f; v[1] = bf16hi(x[0]) > 0.f ? v[1] : 0.f;
