@@ -22,7 +22,7 @@ GEMM_MAX_PROBLEMS, ATTN_MAX_PROBLEMS, LN_MAX_PROBLEMS, COLSUM_MAX_PROBLEMS = 24,
 # every symbol include/mmfusion.h declares (tests check the .so exports all of them)
 SYMBOLS = (
     "mmf_version", "mmf_last_error", "mmf_device_cu_count", "mmf_gemm_grouped", "mmf_gemm_grouped_ex", "mmf_gemm_select_impl",
-    "mmf_attn_fwd_grouped_ex", "mmf_attn_bwd_grouped_ex", "mmf_dropout",
+    "mmf_attn_fwd_grouped_ex", "mmf_attn_bwd_grouped_ex", "mmf_dropout", "mmf_attn_select_impl",
     "mmf_attn_fwd_grouped", "mmf_attn_bwd_grouped", "mmf_layernorm_fwd_grouped",
     "mmf_layernorm_bwd_grouped", "mmf_layernorm_bwd_workspace_bytes", "mmf_cast_f32_to_bf16", "mmf_cast_bf16_to_f32", "mmf_add3_bf16",
     "mmf_meanpool_fwd", "mmf_meanpool_bwd", "mmf_colsum_bf16", "mmf_colsum_grouped", "mmf_relu_bwd_bf16",
@@ -89,6 +89,7 @@ def load() -> C.CDLL:
     lib.mmf_attn_bwd_grouped_ex.argtypes = [C.POINTER(AttnProblem), i32, i32, f32, f32, vp, C.c_uint32, vp]
     lib.mmf_dropout.argtypes = [vp, vp, i64, i32, f32, vp, C.c_uint32, vp]
     lib.mmf_attn_fwd_grouped.argtypes = [C.POINTER(AttnProblem), i32, i32, f32, vp]
+    lib.mmf_attn_select_impl.argtypes = [i32]
     lib.mmf_attn_bwd_grouped.argtypes = [C.POINTER(AttnProblem), i32, i32, f32, vp]
     lib.mmf_layernorm_fwd_grouped.argtypes = [C.POINTER(LnProblem), i32, i32, f32, vp]
     lib.mmf_layernorm_bwd_grouped.argtypes = [C.POINTER(LnProblem), i32, i32, vp, C.c_size_t, vp]

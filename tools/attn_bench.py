@@ -1,47 +1,92 @@
 #!/usr/bin/env python3
-"""Attention microbench on the MulT shapes (six cross problems / three self problems in one launch)."""
-import os, sys
+"""Attention microbench on the MulT shapes (six cross problems / three self problems in one launch).
+
+Calls the C ABI directly (no autograd, no allocation in the timed region); each measurement is one hipGraph
+holding INNER back-to-back launches, replayed REPS times, so launch gaps do not enter the number.
+    python tools/attn_bench.py [fwd|bwd|both]       MMF_ATTN_IMPLS=1,2 selects the generations to compare
+"""
+import ctypes as C
+import os
+import sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "simple-multimodal_amd"))
 import torch
-from mmfusion import ops
+from mmfusion import lib
+
 B, H, dh, d = 16, 8, 96, 768
 T = dict(t=512, a=400, v=30)
-def run(pairs, bwd, reps=20):
-    srcs, specs = [], []
+INNER, REPS = 10, 10
+
+
+def problems(pairs, bwd):
+    keep, arr = [], (lib.AttnProblem * len(pairs))()
     for i, (q, k) in enumerate(pairs):
-        srcs.append(torch.randn(B * T[q], d, device="cuda").bfloat16().requires_grad_(bwd))
-        srcs.append(torch.randn(B * T[k], 2 * d, device="cuda").bfloat16().requires_grad_(bwd))
-        specs.append(ops.AttnSpec(B, T[q], T[k], q=(2 * i, 0), k=(2 * i + 1, 0), v=(2 * i + 1, d)))
-    gos = None
+        Q = torch.randn(B * T[q], d, device="cuda").bfloat16()
+        KV = torch.randn(B * T[k], 2 * d, device="cuda").bfloat16()
+        O = torch.empty_like(Q)
+        LSE = torch.empty(B * H * T[q], device="cuda")
+        dO, dQ, dKV = torch.randn_like(Q), torch.empty_like(Q), torch.empty_like(KV)
+        delta = torch.empty_like(LSE)
+        keep += [Q, KV, O, LSE, dO, dQ, dKV, delta]
+        p = arr[i]
+        p.Q, p.K, p.V, p.O, p.LSE = Q.data_ptr(), KV.data_ptr(), KV.data_ptr() + 2 * d, O.data_ptr(), LSE.data_ptr()
+        p.dO, p.delta, p.dQ, p.dK, p.dV = dO.data_ptr(), delta.data_ptr(), dQ.data_ptr(), dKV.data_ptr(), dKV.data_ptr() + 2 * d
+        p.B, p.H, p.Tq, p.Tk = B, H, T[q], T[k]
+        p.ldq, p.ldk, p.ldv, p.ldo = d, 2 * d, 2 * d, d
+    return arr, keep
+
+
+def run(pairs, bwd):
+    L = lib.load()
+    arr, keep = problems(pairs, bwd)
+    scale = dh ** -0.5
+    fn = L.mmf_attn_bwd_grouped if bwd else L.mmf_attn_fwd_grouped
+
     def once():
-        outs = ops.attention_group(specs, H, dh, srcs)
-        if bwd:
-            torch.autograd.backward(outs, [torch.ones_like(o) for o in outs])
+        lib.check(fn(arr, len(pairs), dh, scale, lib.stream_ptr()))
+    if bwd:                                   # LSE must be valid
+        lib.check(L.mmf_attn_fwd_grouped(arr, len(pairs), dh, scale, lib.stream_ptr()))
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
-        for _ in range(3): once()
+        for _ in range(3):
+            once()
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
-    g = torch.cuda.CUDAGraph()            # replay: no host launch overhead in the measurement
+    g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
-        once()
-    g.replay(); torch.cuda.synchronize()
+        for _ in range(INNER):
+            once()
+    g.replay()
+    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(reps): g.replay()
-    e1.record(); torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) * 1e3 / reps
-    fl = sum(4.0 * B * H * T[q] * T[k] * dh for q, k in pairs) * (3 if bwd else 1)
+    for _ in range(REPS):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / (REPS * INNER)
+    fl = sum(4.0 * B * H * T[q] * T[k] * dh for q, k in pairs) * (2 if bwd else 1)
     return us, fl / us / 1e6
+
+
 cross = [("t", "a"), ("t", "v"), ("a", "t"), ("a", "v"), ("v", "t"), ("v", "a")]
 selfp = [("t", "t"), ("a", "a"), ("v", "v")]
-tag = os.environ.get("MMF_ATTN_DEBUG", "0")
-for name, pairs in [("cross x6", cross), ("self x3", selfp), ("t<-a only", [("t", "a")]), ("t<-t only", [("t", "t")])]:
-    us, tf = run(pairs, False)
-    print(f"dbg{tag} fwd {name:10s} {us:8.1f} us {tf:7.1f} TF", flush=True)
-if tag == "0":
-    for name, pairs in [("cross x6", cross), ("self x3", selfp)]:
-        us, tf = run(pairs, True)
-        print(f"dbg{tag} fwd+bwd {name:10s} {us:8.1f} us {tf:7.1f} TF(3x fwd flops)", flush=True)
+what = sys.argv[1] if len(sys.argv) > 1 else "fwd"
+impls = [int(x) for x in os.environ.get("MMF_ATTN_IMPLS", "1,2").split(",")]
+cases = [("cross x6", cross), ("self x3", selfp), ("t<-a only", [("t", "a")]), ("a<-t only", [("a", "t")]),
+         ("t<-t only", [("t", "t")]), ("v<-t only", [("v", "t")]), ("t<-v only", [("t", "v")])]
+if os.environ.get("MMF_ATTN_CASES"):
+    want = os.environ["MMF_ATTN_CASES"].split(",")
+    cases = [c for c in cases if c[0].split()[0] in want]
+if os.environ.get("MMF_ATTN_B"):
+    B = int(os.environ["MMF_ATTN_B"])
+for bwd in ([False] if what == "fwd" else [True] if what == "bwd" else [False, True]):
+    for name, pairs in cases:
+        row = f"{'bwd' if bwd else 'fwd'} {name:10s}"
+        for impl in impls:
+            lib.check(lib.load().mmf_attn_select_impl(impl))
+            us, tf = run(pairs, bwd)
+            row += f"   impl{impl} {us:7.1f} us {tf:6.1f} TF"
+        print(row + ("   (bwd credited 8 Tq Tk d)" if bwd else ""), flush=True)
+lib.check(lib.load().mmf_attn_select_impl(0))
