@@ -89,9 +89,10 @@ def make_train_step(model, xs, arena, world, allreduce, rank):
     labels = torch.randint(0, 7, (xs[0].shape[0],), generator=g).to(xs[0].device)
 
     def fwd_bwd():
-        arena.zero_grad(overlap=True)
+        arena.zero_grad(overlap=True, lazy=True)
         out = model(*xs, compute_contrastive_loss=True)
         fusion_loss(out, labels).backward()
+        arena.finalize_grads()
 
     def before_replay():
         opt.set_hparams(lr=one_cycle_lr(opt.t, 100000, 1e-4))
@@ -105,9 +106,10 @@ def make_train_step(model, xs, arena, world, allreduce, rank):
 def make_step(workload, model, xs, arena):
     def step():
         # the module's own entry hook re-casts the fp32 masters to the bf16 shadow on every training
-        # forward (what autocast does per forward), so the cast is inside the timed step; the gradient
-        # arena is zeroed on the arena's side stream (joined inside the forward, before any backward kernel)
-        arena.zero_grad(overlap=True)
+        # forward (what autocast does per forward), so the cast is inside the timed step; gradients are
+        # zeroed lazily: vectors by memset, matrices by the first wgrad GEMM of the step overwriting
+        # (ParamArena.zero_grad(lazy=True); finalize_grads() zeroes any matrix no wgrad wrote)
+        arena.zero_grad(overlap=True, lazy=True)
         if workload == "mult":
             out = model(*xs)
             loss = out["fused_features"].sum()
@@ -115,6 +117,7 @@ def make_step(workload, model, xs, arena):
             out = model(*xs, compute_contrastive_loss=True)
             loss = out["fused_features"].sum() + 0.1 * sum(out["contrastive_losses"].values())
         loss.backward()
+        arena.finalize_grads()
         return loss
     return step
 

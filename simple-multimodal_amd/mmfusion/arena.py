@@ -34,6 +34,22 @@ ALIGN = 64
 OVERLAP = os.environ.get("MMF_OVERLAP", "0") == "1"
 
 
+# zero_grad(lazy=True): first-touch overwrite by the wgrad GEMMs instead of a 4 B/param memset (MMF_LAZY_ZERO=0: off)
+LAZY_ZERO = os.environ.get("MMF_LAZY_ZERO", "1") != "0"
+import weakref
+_ARENAS: "weakref.WeakSet[ParamArena]" = weakref.WeakSet()
+
+
+def arena_of(grad: torch.Tensor) -> Optional["ParamArena"]:
+    """The arena whose gradient buffer contains ``grad`` (ops.queue_wgrad: first-touch overwrite)."""
+    ptr = grad.data_ptr()
+    for a in _ARENAS:
+        base = a.grads.data_ptr()
+        if base <= ptr < base + 4 * a.numel:
+            return a
+    return None
+
+
 def _is_early(name: str) -> bool:
     """Parameters the first launches of a forward read: attention in-projections.  They are laid out at
     the front of the arena so that their bf16 cast can run first while the rest streams on a side stream."""
@@ -49,7 +65,10 @@ class ParamArena:
                 named.append((n, p))
         if not named:
             raise ValueError("module has no parameters")
-        named.sort(key=lambda np_: 0 if _is_early(np_[0]) else 1)      # stable: early block first
+        # stable: attention in-projections first, then the other matrices, then the vectors (biases, LayerNorm):
+        # the matrices' gradients are produced by the wgrad GEMMs, which can overwrite instead of accumulate
+        # (zero_grad(lazy=True)), so what still needs a memset each step is the contiguous tail
+        named.sort(key=lambda np_: 0 if _is_early(np_[0]) else (1 if np_[1].dim() >= 2 else 2))
         params: List[torch.nn.Parameter] = [p for _, p in named]
         n_early = sum(1 for n, _ in named if _is_early(n))
         dev = params[0].device
@@ -79,6 +98,11 @@ class ParamArena:
                 p._mmf_bf16 = self.shadow[o:o + n].view(p.shape)
                 p._mmf_arena = self
                 p._mmf_late = o >= self.early_numel
+        _ARENAS.add(self)
+        # gradient regions (element offset -> numel) a wgrad GEMM has produced: whole matrices, or row blocks
+        # of one (the q and kv parts of a cross-attention in_proj_weight are written by separate GEMMs)
+        self._managed: Dict[int, int] = {}
+        self._lazy: Optional[set] = None    # lazy zeroing in force: managed regions not written yet this step
         self.attach_grads()
         self._cast_version = None
         self.refresh(force=True)
@@ -118,16 +142,89 @@ class ParamArena:
             torch.cuda.current_stream().wait_stream(self._side)
             self._pending = False
 
-    def zero_grad(self, overlap: bool = False) -> None:
+    def zero_grad(self, overlap: bool = False, lazy: bool = False) -> None:
         """overlap=True enqueues the 4 B/param memset on the side stream; it is joined before the first
         late weight is read in the NEXT forward, i.e. long before any backward kernel accumulates.  Only
-        for callers that run forward right after (bench.py, mmfusion.train)."""
+        for callers that run forward right after (bench.py, mmfusion.train).
+
+        lazy=True (training-step harnesses; the caller MUST call ``finalize_grads()`` after backward and
+        before anything reads the gradients): matrices whose gradient the wgrad GEMMs produced in earlier
+        steps are not memset — the first wgrad of the step overwrites (``ops.queue_wgrad`` asks
+        ``take_first_touch``), later ones accumulate, and ``finalize_grads`` zeroes any that received
+        nothing.  Everything else (biases, LayerNorm, torch-produced gradients) is zeroed here as a few
+        contiguous ranges.  Saves the 4 B/param memset and the wgrad epilogue's read of the old value."""
+        if lazy and LAZY_ZERO and self._managed and self.grads.is_cuda:
+            self.join()
+            for s0, e0 in self._unmanaged_ranges():
+                self.grads[s0:e0].zero_()
+            self._lazy = set(self._managed)
+            return
+        self._lazy = None
         if overlap and OVERLAP and self.grads.is_cuda:
             with torch.cuda.stream(self._fork()):
                 self.grads.zero_()
         else:
             self.join()
             self.grads.zero_()
+
+    def _unmanaged_ranges(self) -> List[tuple]:
+        """Complement of the managed regions in [0, numel), as coalesced (start, end) element ranges."""
+        cached = getattr(self, "_ranges_cache", None)
+        if cached is not None and cached[0] == len(self._managed):
+            return cached[1]
+        ranges, pos = [], 0
+        for o in sorted(self._managed):
+            if o > pos:
+                ranges.append((pos, o))
+            pos = max(pos, o + self._managed[o])
+        if pos < self.numel:
+            ranges.append((pos, self.numel))
+        # alignment gaps between parameters hold no gradient: drop ranges that are nothing but padding
+        ends = sorted(o + p.numel() for o, p in zip(self.offsets, self.params))
+        starts = sorted(self.offsets)
+        import bisect
+
+        def only_padding(s0, e0):
+            i = bisect.bisect_right(starts, s0) - 1          # parameter containing or preceding s0
+            return i >= 0 and s0 >= ends[i] and (i + 1 >= len(starts) or e0 <= starts[i + 1])
+        ranges = [r for r in ranges if not only_padding(*r)]
+        self._ranges_cache = (len(self._managed), ranges)
+        return ranges
+
+    def take_first_touch(self, grad: torch.Tensor) -> bool:
+        """Called by ``ops.queue_wgrad`` with the gradient view a wgrad GEMM is about to produce (a whole
+        parameter or a contiguous row block of one): records the region as wgrad-managed and returns True
+        if the GEMM must OVERWRITE (lazy zeroing in force and nothing has written the region yet this
+        step), False if it must accumulate."""
+        off = (grad.data_ptr() - self.grads.data_ptr()) // 4
+        n = grad.numel()
+        if off < 0 or off + n > self.numel or not grad.is_contiguous():
+            return False
+        known = self._managed.get(off)
+        if known is None:
+            # a new region must not overlap a managed one (then it keeps accumulating onto memset zeros)
+            for o, m in self._managed.items():
+                if o < off + n and off < o + m:
+                    if self._lazy is not None and o in self._lazy:     # stale values underneath: zero them now
+                        self.grads[o:o + m].zero_()
+                        self._lazy.discard(o)
+                    return False
+            if self._lazy is None:
+                self._managed[off] = n
+            return False
+        if known != n:
+            return False
+        if self._lazy is not None and off in self._lazy:
+            self._lazy.discard(off)
+            return True
+        return False
+
+    def finalize_grads(self) -> None:
+        """End of a lazily-zeroed backward: managed regions no wgrad wrote this step hold stale values."""
+        if self._lazy:
+            for off in sorted(self._lazy):
+                self.grads[off:off + self._managed[off]].zero_()
+        self._lazy = None
 
     # -- bf16 shadow ---------------------------------------------------------------------------
     def _version(self) -> int:

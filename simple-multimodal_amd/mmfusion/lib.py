@@ -112,6 +112,9 @@ def load() -> C.CDLL:
     if lib.mmf_version() != 1:
         raise RuntimeError(f"libmmfusion ABI version {lib.mmf_version()} != 1")
     _lib = lib
+    for env, fn in (("MMF_ATTN_IMPL", lib.mmf_attn_select_impl), ("MMF_GEMM_IMPL", lib.mmf_gemm_select_impl)):
+        if os.environ.get(env):            # A/B runs: pin a kernel generation for the whole process
+            check(fn(int(os.environ[env])))
     return lib
 
 

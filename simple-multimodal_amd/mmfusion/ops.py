@@ -223,23 +223,32 @@ _pending_wgrad: List[tuple] = []
 def _flush_wgrad() -> None:
     global _pending_wgrad
     pend, _pending_wgrad = _pending_wgrad, []
-    with_bias = [p for p in pend if p[3] is not None]
-    without = [p for p in pend if p[3] is None]
+    # (has bias, overwrite) -> problems; overwrite = first wgrad of a lazily-zeroed step (arena.zero_grad(lazy=True))
+    groups: dict = {}
+    for q in pend:
+        groups.setdefault((q[3] is not None, q[5]), []).append(q[:5])
     # big problems first: the tail of the launch is then made of small tiles
-    for group, epi in ((with_bias, EPI_ACCUM | EPI_COLSUM_A), (without, EPI_ACCUM)):
-        if group:
-            group.sort(key=lambda t: -(t[2].shape[0] * t[2].shape[1] * t[0].shape[0]))
-            gemm_group(GEMM_TN, group, epi)
+    for (has_bias, overwrite), group in sorted(groups.items(), key=lambda kv: (not kv[0][0], not kv[0][1])):
+        group.sort(key=lambda t: -(t[2].shape[0] * t[2].shape[1] * t[0].shape[0]))
+        gemm_group(GEMM_TN, group, (0 if overwrite else EPI_ACCUM) | (EPI_COLSUM_A if has_bias else 0))
 
 
 def queue_wgrad(dy: torch.Tensor, x: torch.Tensor, wgrad: torch.Tensor, bgrad: Optional[torch.Tensor]) -> None:
-    """wgrad (f32, [N_out, K_in]) += dy^T x ;  bgrad (f32 [N_out]) += column sums of dy."""
+    """wgrad (f32, [N_out, K_in]) += dy^T x ;  bgrad (f32 [N_out]) += column sums of dy.
+    If the gradient lives in an arena that was zeroed lazily this step and nothing has written it yet, the
+    GEMM overwrites instead (``ParamArena.take_first_touch``)."""
+    overwrite = False
+    from .arena import arena_of
+    ar = arena_of(wgrad)
+    if ar is not None:
+        overwrite = ar.take_first_touch(wgrad)
     if not DEFER_WGRAD:
-        gemm_group(GEMM_TN, [(dy, x, wgrad, bgrad, None)], EPI_ACCUM | (EPI_COLSUM_A if bgrad is not None else 0))
+        gemm_group(GEMM_TN, [(dy, x, wgrad, bgrad, None)],
+                   (0 if overwrite else EPI_ACCUM) | (EPI_COLSUM_A if bgrad is not None else 0))
         return
     if not _pending_wgrad:
         torch.autograd.Variable._execution_engine.queue_callback(_flush_wgrad)
-    _pending_wgrad.append((dy, x, wgrad, bgrad, None))
+    _pending_wgrad.append((dy, x, wgrad, bgrad, None, overwrite))
 
 
 # --------------------------------------------------------------------------------------------

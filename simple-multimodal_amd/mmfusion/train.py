@@ -113,7 +113,7 @@ class FusionTrainStep:
         self.world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
 
     def fwd_bwd(self, text, audio, video, targets) -> torch.Tensor:
-        self.arena.zero_grad(overlap=True)
+        self.arena.zero_grad(overlap=True, lazy=True)
         kw = {"compute_contrastive_loss": True} if self.contrastive else {}
         out = self.model(text, audio, video, **kw)
         fused = out["fused_features"] if isinstance(out, dict) else out
@@ -121,6 +121,7 @@ class FusionTrainStep:
         outputs["emotion_logits"] = self.head(fused)
         loss = fusion_loss(outputs, targets)
         loss.backward()
+        self.arena.finalize_grads()
         return loss
 
     def __call__(self, text, audio, video, targets) -> torch.Tensor:

@@ -304,3 +304,42 @@ def test_skinny_grouped_strided():
     lib.skinny_fwd(probs, 0, False)
     for i in range(3):
         assert rel(ys[i], big[:, 768 * i:768 * (i + 1)].float().cpu() @ ws[i].float().cpu().t()) < 2 ** -8
+
+
+def test_lazy_zero_grad_is_bit_identical_and_zeroes_untouched_matrices():
+    """ParamArena.zero_grad(lazy=True): the first wgrad GEMM of a step overwrites instead of accumulating
+    onto a memset; gradients must be bit-identical to the eager-zero step, and a wgrad-managed matrix that
+    receives no gradient in a later step (contrastive projectors when the loss is off) must read zero
+    after finalize_grads()."""
+    import config as cfgmod
+    from mmfusion import arena as arena_mod
+    from models import fusion_layers as fl
+    cfg = cfgmod.ModelConfig()
+    cfg.fusion_hidden_size, cfg.fusion_num_heads, cfg.fusion_dropout = 128, 2, 0.0
+    torch.manual_seed(3)
+    m = fl.ContrastiveFusion(cfg).cuda().train()
+    ar = arena_mod.ensure(m)
+    xs = [torch.randn(16, 128, device="cuda") for _ in range(3)]
+
+    def step(lazy, contrastive):
+        ar.zero_grad(lazy=lazy)
+        out = m(*xs, compute_contrastive_loss=contrastive)
+        loss = out["fused_features"].sum()
+        if contrastive:
+            loss = loss + sum(out["contrastive_losses"].values())
+        loss.backward()
+        ar.finalize_grads()
+        torch.cuda.synchronize()
+        return ar.grads.clone()
+
+    g_eager = step(False, True)                 # also teaches the arena which matrices the wgrad GEMMs own
+    assert ar._managed, "no wgrad-managed parameters recorded"
+    ar.grads.fill_(7.0)                         # stale values a lazy zero must not let through
+    g_lazy = step(True, True)
+    assert torch.equal(g_eager, g_lazy)
+    g_eager2 = step(False, False)               # projector weights get no gradient now
+    ar.grads.fill_(7.0)
+    g_lazy2 = step(True, False)
+    assert torch.equal(g_eager2, g_lazy2)
+    proj = [p for n, p in m.named_parameters() if "projector" in n and p.dim() == 2]
+    assert proj and all(float(p.grad.abs().max()) == 0.0 for p in proj)
