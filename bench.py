@@ -210,7 +210,7 @@ def kernel_profile(step, nsteps):
         step()
     torch.cuda.synchronize()
     agg = {}
-    for label, flops, e0, e1 in lib.PROFILE:
+    for label, flops, e0, e1, *_ in lib.PROFILE:
         a = agg.setdefault(label, [0.0, 0.0, 0])
         a[0] += e0.elapsed_time(e1)
         a[1] += flops

@@ -479,6 +479,8 @@ int fill_args(AttnArgs& a, const mmf_attn_problem* p, int n, float scale, bool b
 // second generation (attention2.hip)
 int mmf_attn_fwd2_launch(const mmf_attn_problem* problems, int n, int head_dim, float scale, float drop_p,
                          const uint64_t* rng_state, uint32_t site, hipStream_t s);
+int mmf_attn_bwd2_launch(const mmf_attn_problem* problems, int n, int head_dim, float scale, float drop_p,
+                         const uint64_t* rng_state, uint32_t site, hipStream_t s);
 static int g_attn_impl = 0;       // 0 automatic (second generation), 1 first generation, 2 second generation
 extern "C" int mmf_attn_select_impl(int impl) {
   if (impl < 0 || impl > 2) MMF_FAIL(MMF_E_UNSUPPORTED, "mmf_attn_select_impl: impl=%d (0 auto, 1, 2)", impl);
@@ -514,6 +516,8 @@ extern "C" int mmf_attn_bwd_grouped_ex(const mmf_attn_problem* problems, int num
   if (!(dropout_p >= 0.f) || dropout_p >= 1.f || (dropout_p > 0.f && !rng_state))
     MMF_FAIL(MMF_E_SHAPE, "mmf_attn_bwd_grouped_ex: dropout needs 0 <= p < 1 and an rng_state");
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (g_attn_impl != 1 && !getenv("MMF_ATTN_DEBUG"))
+    return mmf_attn_bwd2_launch(problems, num_problems, head_dim, scale, dropout_p, rng_state, site, s);
   AttnArgs a;
   int total = fill_args(a, problems, num_problems, scale, false, dropout_p, rng_state, site);   // dQ (+ delta) first
   const bool dr = a.drop_thresh != 0u;

@@ -29,6 +29,9 @@
 namespace {
 
 constexpr unsigned OOB = 0x80000000u;
+#ifndef DQ_WAVES_PER_SIMD
+#define DQ_WAVES_PER_SIMD 3            // dQ kernel at <= 168 registers: three 4-wave workgroups per CU (3 x 52 KiB of LDS)
+#endif
 constexpr float DEFER = 6.0f;          // log2 domain: P <= 64 before a rescale is forced
 
 struct AttnArgs2 {
@@ -95,14 +98,35 @@ struct PvStep {
   }
 };
 
+// LDS-DMA of one stage = two [64][DH+8] tiles X (at st) and Y (at st + TILE_B) of rows [64 j, 64 j + 64) of two
+// (T, ld) matrices given as buffer descriptors whose range ends after row T-1 (rows past T read as zeros).
+// Piece p = wave + 4 i covers image chunks 64 pc .. 64 pc + 63 of X (p < PIECES) or Y; chunk c is row c / CPR,
+// 16-B column c % CPR (the last column is the pad: explicit out-of-range offset -> zeros).
+template <int DH>
+__device__ __forceinline__ void dma_pair(__amdgpu_buffer_rsrc_t rsX, __amdgpu_buffer_rsrc_t rsY, int ldx, int ldy,
+                                         char* st, int j, int wave, int lane) {
+  constexpr int SB = (DH + 8) * 2, TILE_B = 64 * SB, CPR = DH / 8 + 1, PIECES = TILE_B / 1024, NI = (2 * PIECES + 3) / 4;
+  static_assert(TILE_B % 1024 == 0, "a tile must be a whole number of 1-KiB LDS-DMA pieces");
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int p = wave + 4 * i;
+    if (p < 2 * PIECES) {
+      const int isy = p >= PIECES, c = (p - isy * PIECES) * 64 + lane;
+      const int row = c / CPR, ch = c % CPR;
+      const int ld = isy ? ldy : ldx;
+      const unsigned off = ch == CPR - 1 ? OOB : (unsigned)((64 * j + row) * ld * 2 + ch * 16);
+      if (!isy) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_void_t*)(st + p * 1024), 16, off, 0, 0, 0);
+      else      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, (lds_void_t*)(st + p * 1024), 16, off, 0, 0, 0);
+    }
+  }
+}
+
 // One wave of the forward: NQ (0, 1 or 2) query blocks of 32 rows at rows qs and qs + 128.  Waves with
 // NQ == 0 only take part in the K/V staging and the barriers.
 template <int DH, bool DROP, int NQ>
 __device__ __forceinline__ void fwd2_wave(const AttnArgs2& a, const mmf_attn_problem& P, const int pidx, const int bh,
                                           const int qs, char* smem) {
   constexpr int KS = DH / 16, DT = DH / 32, SB = (DH + 8) * 2, TILE_B = 64 * SB, STAGE_B = 2 * TILE_B;
-  constexpr int CPR = DH / 8 + 1, PIECES = TILE_B / 1024, NI = (2 * PIECES + 3) / 4;
-  static_assert(TILE_B % 1024 == 0, "a K or V tile must be a whole number of 1-KiB LDS-DMA pieces");
   constexpr int NQA = NQ > 0 ? NQ : 1;
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -114,23 +138,7 @@ __device__ __forceinline__ void fwd2_wave(const AttnArgs2& a, const mmf_attn_pro
   const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(Kg), 0, Tk * P.ldk * 2, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(Vg), 0, Tk * P.ldv * 2, 0x00020000);
 
-  // LDS-DMA source offsets of this lane: piece p = wave + 4 i covers image chunks 64 pc .. 64 pc + 63 of the
-  // K (p < PIECES) or V tile; chunk c is row c / CPR, 16-B column c % CPR (the last column is the pad).
-  const unsigned stepK = 64u * P.ldk * 2u, stepV = 64u * P.ldv * 2u;
-  auto issue = [&](int j) {
-    char* st = smem + (j & 1) * STAGE_B;
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const int p = wave + 4 * i;
-      if (p < 2 * PIECES) {
-        const int isv = p >= PIECES, c = (p - isv * PIECES) * 64 + lane;
-        const int row = c / CPR, ch = c % CPR;
-        const unsigned off = ch == CPR - 1 ? OOB : (unsigned)(row * (isv ? P.ldv : P.ldk) * 2 + ch * 16);
-        if (!isv) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (lds_void_t*)(st + p * 1024), 16, off + j * stepK, 0, 0, 0);
-        else      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (lds_void_t*)(st + p * 1024), 16, off + j * stepV, 0, 0, 0);
-      }
-    }
-  };
+  auto issue = [&](int j) { dma_pair<DH>(rsK, rsV, P.ldk, P.ldv, smem + (j & 1) * STAGE_B, j, wave, lane); };
   const int ntiles = (Tk + 63) / 64;
   issue(0);
 
@@ -276,12 +284,286 @@ void attn_fwd2_kernel(const AttnArgs2 a) {
   else              fwd2_wave<DH, DROP, 0>(a, P, pidx, bh, qs, smem);
 }
 
+
+// ================================================================================================
+// backward, second generation.  Same arithmetic as attention.hip's two kernels (dQ + delta, then dK/dV; recompute
+// from LSE; no atomics, deterministic); what changes is how the swept tiles reach the MFMAs:
+//   * K/V (dQ kernel) and Q/dO (+ LSE, delta; dK/dV kernel) tiles arrive by LDS-DMA into a 2-stage ring, the next
+//     tile in flight under the current tile's MFMAs.  The first generation fetched through registers and, in the
+//     dK/dV kernel, only AFTER the MFMAs: one exposed HBM/L2 latency per tile, which made the x30 problems
+//     (one active wave walking 8 tiles) cost 37-41 us each;
+//   * XCD-aware work order, heaviest problem first (see the forward);
+//   * 32-row blocks that hold only padding are skipped;
+//   * transposed operands by asm ds_read_b64_tr_b16 with counted waits, the next fragment in flight under the
+//     current MFMAs.
+// ================================================================================================
+
+// dQ^T += K^T . dS^T for block KT: PvStep with the K tile as the transposed operand
+template <int DH, bool DROP, bool ACTIVE>
+__device__ __forceinline__ void dq2_wave(const AttnArgs2& a, const mmf_attn_problem& P, const int pidx, const int bh,
+                                         const int qs, char* smem) {
+  constexpr int KS = DH / 16, DT = DH / 32, SB = (DH + 8) * 2, TILE_B = 64 * SB, STAGE_B = 2 * TILE_B;
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int Tq = P.Tq, Tk = P.Tk, H = P.H;
+  const int b = bh / H, h = bh % H;
+  const unsigned short* Kg = static_cast<const unsigned short*>(P.K) + (size_t)b * Tk * P.ldk + h * DH;
+  const unsigned short* Vg = static_cast<const unsigned short*>(P.V) + (size_t)b * Tk * P.ldv + h * DH;
+  const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(Kg), 0, Tk * P.ldk * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(Vg), 0, Tk * P.ldv * 2, 0x00020000);
+  auto issue = [&](int j) { dma_pair<DH>(rsK, rsV, P.ldk, P.ldv, smem + (j & 1) * STAGE_B, j, wave, lane); };
+  const int ntiles = (Tk + 63) / 64;
+  issue(0);
+
+  const int qrow = qs + (lane & 31);
+  const size_t qoff = (size_t)b * Tq * P.ldq + h * DH, ooff = (size_t)b * Tq * P.ldo + h * DH;
+  char* slice = smem + STAGE_B + wave * (32 * SB);
+  bf16x8_t qf[KS], dof[KS];
+  float delta = 0.f, lse2 = 0.f;
+  if constexpr (ACTIVE) {
+    load_row_frags_lds<DH>(qf, static_cast<const unsigned short*>(P.Q) + qoff, P.ldq, qs, Tq, lane, slice);
+    load_row_frags_lds<DH>(dof, static_cast<const unsigned short*>(P.dO) + ooff, P.ldo, qs, Tq, lane, slice);
+    bf16x8_t of[KS];
+    load_row_frags_lds<DH>(of, static_cast<const unsigned short*>(P.O) + ooff, P.ldo, qs, Tq, lane, slice);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const u32x4_t x = __builtin_bit_cast(u32x4_t, of[ks]), y = __builtin_bit_cast(u32x4_t, dof[ks]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) delta += bf16lo(x[e]) * bf16lo(y[e]) + bf16hi(x[e]) * bf16hi(y[e]);
+    }
+    delta += __shfl_xor(delta, 32, 64);
+    if (half == 0 && qrow < Tq) P.delta[(size_t)bh * Tq + qrow] = delta;
+    lse2 = (qrow < Tq ? P.LSE[(size_t)bh * Tq + qrow] : 0.f) * LOG2E;
+  }
+  const float c = a.scale * LOG2E;
+  const unsigned dkey = DROP ? mmf_rng_key(*a.rng_state, a.site, (unsigned)(pidx * 4096 + bh)) : 0u;
+  const unsigned qidx = (unsigned)qrow * (unsigned)Tk;
+  f32x16_t dq[1][DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[0][dt][r] = 0.f;
+  const unsigned troff = (unsigned)((4 * half + ((lane >> 2) & 3)) * SB + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2);
+  const unsigned smem_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+
+  for (int j = 0; j < ntiles; ++j) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (j + 1 < ntiles) issue(j + 1);
+    if constexpr (ACTIVE) {
+      const char* sK = smem + (j & 1) * STAGE_B;
+      const char* sV = sK + TILE_B;
+      const unsigned vaK = smem_lds + (j & 1) * STAGE_B + troff;
+      auto block = [&](auto KTc) {
+        constexpr int KT = decltype(KTc)::value;
+        const int k0 = j * 64 + 32 * KT;
+        if (k0 >= Tk) return;
+        f32x16_t s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<DH>(sK, 32 * KT, ks, lane), qf[ks], s, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<DH>(sV, 32 * KT, ks, lane), dof[ks], dp, 0, 0, 0);
+        }
+        s16x4_t lo, hi;
+        tr_issue<DH, 2 * KT, 0>(vaK, lo, hi);
+        const bool ragged = k0 + 32 > Tk;
+        f32x16_t ds[1];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float p = fast_exp2(__builtin_fmaf(s[r], c, -lse2));
+          const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (ragged) p = key < Tk ? p : 0.f;
+          float dpv = dp[r];                                // d(P_dropped) -> dP through the same mask
+          if (DROP) dpv = mmf_keep(dkey, qidx + (unsigned)key, a.drop_thresh) ? dpv * a.inv_keep : 0.f;
+          ds[0][r] = p * (dpv - delta);                     // dS^T (scale applied at the store)
+        }
+        bf16x8_t pf[1];
+        PvStep<DH, 1, KT, 0>::run(vaK, lo, hi, ds, pf, dq);
+      };
+      block(std::integral_constant<int, 0>{});
+      block(std::integral_constant<int, 1>{});
+    }
+  }
+  if constexpr (ACTIVE) {
+    char* oslice = smem + (ntiles & 1) * STAGE_B + wave * (32 * SB);
+    store_rows_lds<DH>(dq[0], a.scale, static_cast<unsigned short*>(P.dQ) + qoff, P.ldq, qs, Tq, lane, oslice);
+  }
+}
+
+template <int DH, bool DROP>
+__global__ __launch_bounds__(NT, DQ_WAVES_PER_SIMD)
+void attn_bwd_dq2_kernel(const AttnArgs2 a) {
+  constexpr int STAGE_B = 2 * 64 * (DH + 8) * 2;
+  __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE_B];
+  const int bid = blockIdx.x;
+  int pi = 0;
+  while (pi + 1 < a.nprob && bid >= a.blk_start[pi + 1]) ++pi;
+  const int loc = bid - a.blk_start[pi], n8 = (a.blk_start[pi + 1] - a.blk_start[pi]) >> 3;
+  const int item = (loc & 7) * n8 + (loc >> 3);
+  if (item >= a.nwg[pi]) return;
+  const mmf_attn_problem& P = a.p[pi];
+  const int nchunk = a.nchunk[pi];
+  const int bh = item / nchunk, q0 = (item % nchunk) * 128;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int qs = q0 + 32 * wave, pidx = a.orig[pi];
+  if (qs < P.Tq) dq2_wave<DH, DROP, true>(a, P, pidx, bh, qs, smem);
+  else           dq2_wave<DH, DROP, false>(a, P, pidx, bh, qs, smem);
+}
+
+// dV^T += dO^T . P and dK^T += Q^T . dS for the 32 query rows of block QS: 4 DT fragment steps alternating the
+// dO tile (va) and the Q tile (va - TILE_B... given separately), the next fragment in flight under this step's MFMA
+template <int DH, int QS, int N>
+struct DkvStep {
+  static constexpr int DT = DH / 32, NF = 4 * DT;            // step N: ss = N / (2 DT), dt = (N / 2) % DT, operand N & 1
+  static __device__ __forceinline__ void run(unsigned vaQ, unsigned vadO, s16x4_t lo, s16x4_t hi, const f32x16_t& pm,
+                                             const f32x16_t& dsm, bf16x8_t& pf, bf16x8_t& dsf,
+                                             f32x16_t (&dv)[DT], f32x16_t (&dk)[DT]) {
+    s16x4_t nlo, nhi;
+    if constexpr (N + 1 < NF) {
+      constexpr int M = N + 1;
+      tr_issue<DH, 2 * QS + M / (2 * DT), (M / 2) % DT>((M & 1) ? vaQ : vadO, nlo, nhi);
+    }
+    tr_wait<(N + 1 < NF) ? 2 : 0>(lo, hi);
+    const bf16x8_t f = join(lo, hi);
+    if constexpr (N % (2 * DT) == 0) { pf = acc_frag(pm, N / (2 * DT)); dsf = acc_frag(dsm, N / (2 * DT)); }
+    constexpr int dt = (N / 2) % DT;
+    if constexpr ((N & 1) == 0) dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f, pf, dv[dt], 0, 0, 0);
+    else                        dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f, dsf, dk[dt], 0, 0, 0);
+    if constexpr (N + 1 < NF) DkvStep<DH, QS, N + 1>::run(vaQ, vadO, nlo, nhi, pm, dsm, pf, dsf, dv, dk);
+  }
+};
+
+template <int DH, bool DROP, bool ACTIVE>
+__device__ __forceinline__ void dkv2_wave(const AttnArgs2& a, const mmf_attn_problem& P, const int pidx, const int bh,
+                                          const int k0, char* smem) {
+  constexpr int KS = DH / 16, DT = DH / 32, SB = (DH + 8) * 2, TILE_B = 64 * SB, STAGE_B = 2 * TILE_B;
+  constexpr int STAT_OFF = 2 * STAGE_B;                      // [stage][lse 64 | delta 64] f32 behind the two stages
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int Tq = P.Tq, Tk = P.Tk, H = P.H;
+  const int b = bh / H, h = bh % H;
+  const unsigned short* Qg = static_cast<const unsigned short*>(P.Q) + (size_t)b * Tq * P.ldq + h * DH;
+  const unsigned short* dOg = static_cast<const unsigned short*>(P.dO) + (size_t)b * Tq * P.ldo + h * DH;
+  const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(Qg), 0, Tq * P.ldq * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsdO = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(dOg), 0, Tq * P.ldo * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsL = __builtin_amdgcn_make_buffer_rsrc(P.LSE + (size_t)bh * Tq, 0, Tq * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc(P.delta + (size_t)bh * Tq, 0, Tq * 4, 0x00020000);
+  auto issue = [&](int j) {
+    dma_pair<DH>(rsQ, rsdO, P.ldq, P.ldo, smem + (j & 1) * STAGE_B, j, wave, lane);
+    // LSE and delta of the tile's 64 query rows: one 256-B piece each (4 B per lane; rows past Tq read as 0,
+    // which is harmless: their Q and dO rows are zeros, so P = 1 meets dO = 0 and dS = 1 * (0 - 0))
+    char* st = smem + STAT_OFF + (j & 1) * 512;
+    if (wave == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsL, (lds_void_t*)st, 4, (unsigned)(64 * j + lane) * 4u, 0, 0, 0);
+    if (wave == 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsD, (lds_void_t*)(st + 256), 4, (unsigned)(64 * j + lane) * 4u, 0, 0, 0);
+  };
+  const int ntiles = (Tq + 63) / 64;
+  issue(0);
+
+  const size_t koff = (size_t)b * Tk * P.ldk + h * DH, voff = (size_t)b * Tk * P.ldv + h * DH;
+  char* slice = smem + STAGE_B + wave * (32 * SB);
+  bf16x8_t kf[KS], vf[KS];
+  if constexpr (ACTIVE) {
+    load_row_frags_lds<DH>(kf, static_cast<const unsigned short*>(P.K) + koff, P.ldk, k0, Tk, lane, slice);
+    load_row_frags_lds<DH>(vf, static_cast<const unsigned short*>(P.V) + voff, P.ldv, k0, Tk, lane, slice);
+  }
+  f32x16_t dk[DT], dv[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
+  const float c = a.scale * LOG2E;
+  const unsigned dkey = DROP ? mmf_rng_key(*a.rng_state, a.site, (unsigned)(pidx * 4096 + bh)) : 0u;
+  const unsigned kcol = (unsigned)(k0 + (lane & 31));
+  const unsigned troff = (unsigned)((4 * half + ((lane >> 2) & 3)) * SB + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2);
+  const unsigned smem_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+
+  for (int j = 0; j < ntiles; ++j) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (j + 1 < ntiles) issue(j + 1);
+    if constexpr (ACTIVE) {
+      const char* sQ = smem + (j & 1) * STAGE_B;
+      const char* sdO = sQ + TILE_B;
+      const float* sl = reinterpret_cast<const float*>(smem + STAT_OFF + (j & 1) * 512);
+      const unsigned vaQ = smem_lds + (j & 1) * STAGE_B + troff, vadO = vaQ + TILE_B;
+      auto block = [&](auto QSc) {
+        constexpr int QS = decltype(QSc)::value;
+        const int q0 = j * 64 + 32 * QS;
+        if (q0 >= Tq) return;
+        f32x16_t s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<DH>(sQ, 32 * QS, ks, lane), kf[ks], s, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<DH>(sdO, 32 * QS, ks, lane), vf[ks], dp, 0, 0, 0);
+        }
+        s16x4_t lo, hi;
+        tr_issue<DH, 2 * QS, 0>(vadO, lo, hi);
+        f32x16_t ds;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4_t l4 = *reinterpret_cast<const f32x4_t*>(sl + 32 * QS + 8 * g + 4 * half);
+          const f32x4_t d4 = *reinterpret_cast<const f32x4_t*>(sl + 64 + 32 * QS + 8 * g + 4 * half);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float p = fast_exp2(__builtin_fmaf(s[4 * g + i], c, -l4[i] * LOG2E));
+            float pd = p, dpv = dp[4 * g + i];
+            if (DROP) {
+              const unsigned q = (unsigned)(q0 + 8 * g + 4 * half + i);
+              const bool keep = mmf_keep(dkey, q * (unsigned)Tk + kcol, a.drop_thresh);
+              pd = keep ? p * a.inv_keep : 0.f;
+              dpv = keep ? dpv * a.inv_keep : 0.f;
+            }
+            s[4 * g + i] = pd;                            // dV^T += dO^T . P_dropped
+            ds[4 * g + i] = p * (dpv - d4[i]);
+          }
+        }
+        bf16x8_t pf, dsf;
+        DkvStep<DH, QS, 0>::run(vaQ, vadO, lo, hi, s, ds, pf, dsf, dv, dk);
+      };
+      block(std::integral_constant<int, 0>{});
+      block(std::integral_constant<int, 1>{});
+    }
+  }
+  if constexpr (ACTIVE) {
+    char* oslice = smem + (ntiles & 1) * STAGE_B + wave * (32 * SB);
+    store_rows_lds<DH>(dk, a.scale, static_cast<unsigned short*>(P.dK) + koff, P.ldk, k0, Tk, lane, oslice);
+    store_rows_lds<DH>(dv, 1.f, static_cast<unsigned short*>(P.dV) + voff, P.ldv, k0, Tk, lane, oslice);
+  }
+}
+
+template <int DH, bool DROP>
+__global__ __launch_bounds__(NT, 2)      // dK^T, dV^T, K and V fragments alone are 144 registers: two waves per SIMD
+void attn_bwd_dkv2_kernel(const AttnArgs2 a) {
+  constexpr int STAGE_B = 2 * 64 * (DH + 8) * 2;
+  __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE_B + 2 * 512];
+  const int bid = blockIdx.x;
+  int pi = 0;
+  while (pi + 1 < a.nprob && bid >= a.blk_start[pi + 1]) ++pi;
+  const int loc = bid - a.blk_start[pi], n8 = (a.blk_start[pi + 1] - a.blk_start[pi]) >> 3;
+  const int item = (loc & 7) * n8 + (loc >> 3);
+  if (item >= a.nwg[pi]) return;
+  const mmf_attn_problem& P = a.p[pi];
+  const int nchunk = a.nchunk[pi];
+  const int bh = item / nchunk, kc0 = (item % nchunk) * 128;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int k0 = kc0 + 32 * wave, pidx = a.orig[pi];
+  if (k0 < P.Tk) dkv2_wave<DH, DROP, true>(a, P, pidx, bh, k0, smem);
+  else           dkv2_wave<DH, DROP, false>(a, P, pidx, bh, k0, smem);
+}
+
 }  // namespace
 
-// Called by mmf_attn_fwd_grouped_ex (attention.hip) after validation when the second generation is selected.
-int mmf_attn_fwd2_launch(const mmf_attn_problem* problems, int n, int head_dim, float scale, float drop_p,
-                         const uint64_t* rng_state, uint32_t site, hipStream_t s) {
-  AttnArgs2 a;
+namespace {
+// Work table: problems heaviest first; rows_per_wg rows of the partitioned axis (queries, or keys for the dK/dV
+// kernel) per workgroup, balanced over the chunks; workgroup ranges padded to multiples of 8 for the XCD map.
+int fill_args2(AttnArgs2& a, const mmf_attn_problem* problems, int n, float scale, float drop_p, const uint64_t* rng_state,
+               uint32_t site, int rows_per_wg, bool by_keys, bool balance) {
   a.nprob = n; a.scale = scale;
   a.drop_thresh = (drop_p > 0.f && rng_state) ? mmf_drop_thresh(drop_p) : 0u;
   a.inv_keep = a.drop_thresh ? 1.f / (1.f - (float)a.drop_thresh * (1.f / 4294967296.f)) : 1.f;
@@ -291,17 +573,21 @@ int mmf_attn_fwd2_launch(const mmf_attn_problem* problems, int n, int head_dim, 
   a.debug = dbg ? atoi(dbg) : 0;
   int order[MMF_ATTN_MAX_PROBLEMS];
   for (int i = 0; i < n; ++i) order[i] = i;
-  // heaviest first: work per workgroup ~ rows per chunk x Tk
-  std::stable_sort(order, order + n, [&](int x, int y) {
-    return (long long)std::min(problems[x].Tq, 256) * problems[x].Tk > (long long)std::min(problems[y].Tq, 256) * problems[y].Tk;
-  });
+  // Launch order = longest per-workgroup chain first: a workgroup's duration is set by the length of its sweep
+  // (keys for the forward / dQ kernels, queries for dK/dV), not by its row count, and the narrow problems (30
+  // rows: one active wave walking the whole sweep) are pure latency chains — started first they run beside the
+  // wide problems instead of trailing them on an empty chip.
+  auto key = [&](const mmf_attn_problem& q) {
+    const int part = by_keys ? q.Tk : q.Tq, sweep = by_keys ? q.Tq : q.Tk;
+    return (long long)((sweep + 63) / 64) * 4096 - std::min(part, rows_per_wg);
+  };
+  std::stable_sort(order, order + n, [&](int x, int y) { return key(problems[x]) > key(problems[y]); });
   int total = 0;
   for (int k = 0; k < n; ++k) {
     const mmf_attn_problem& q = problems[order[k]];
-    if ((long long)q.Tk * q.ldk * 2 >= 0x7fffffffLL || (long long)q.Tk * q.ldv * 2 >= 0x7fffffffLL)
-      MMF_FAIL(MMF_E_SHAPE, "mmf_attn_fwd_grouped: Tk*ld exceeds the 2 GiB buffer-descriptor range");
-    const int nchunk = (q.Tq + 255) / 256;
-    const int rpc = (((q.Tq + nchunk - 1) / nchunk) + 31) / 32 * 32;
+    const int part = by_keys ? q.Tk : q.Tq;
+    const int nchunk = (part + rows_per_wg - 1) / rows_per_wg;
+    const int rpc = balance ? (((part + nchunk - 1) / nchunk) + 31) / 32 * 32 : rows_per_wg;
     a.blk_start[k] = total;
     a.nwg[k] = q.B * q.H * nchunk;
     a.nchunk[k] = (short)nchunk; a.rpc[k] = (short)rpc; a.orig[k] = (short)order[k];
@@ -309,6 +595,45 @@ int mmf_attn_fwd2_launch(const mmf_attn_problem* problems, int n, int head_dim, 
     total += (a.nwg[k] + 7) / 8 * 8;
   }
   a.blk_start[n] = total;
+  return total;
+}
+int check_ranges(const char* who, const mmf_attn_problem* p, int n) {
+  for (int i = 0; i < n; ++i) {
+    const long long lim = 0x7fffffffLL;
+    if ((long long)p[i].Tk * p[i].ldk * 2 >= lim || (long long)p[i].Tk * p[i].ldv * 2 >= lim ||
+        (long long)p[i].Tq * p[i].ldq * 2 >= lim || (long long)p[i].Tq * p[i].ldo * 2 >= lim)
+      MMF_FAIL(MMF_E_SHAPE, "%s: T*ld exceeds the 2 GiB buffer-descriptor range", who);
+  }
+  return MMF_OK;
+}
+}  // namespace
+
+int mmf_attn_bwd2_launch(const mmf_attn_problem* problems, int n, int head_dim, float scale, float drop_p,
+                         const uint64_t* rng_state, uint32_t site, hipStream_t s) {
+  if (int rc = check_ranges("mmf_attn_bwd_grouped", problems, n)) return rc;
+  AttnArgs2 a;
+  int total = fill_args2(a, problems, n, scale, drop_p, rng_state, site, 128, false, false);   // dQ (+ delta) first
+  const bool dr = a.drop_thresh != 0u;
+  if (head_dim == 96) { if (dr) hipLaunchKernelGGL((attn_bwd_dq2_kernel<96, true>), dim3(total), dim3(NT), 0, s, a);
+                        else    hipLaunchKernelGGL((attn_bwd_dq2_kernel<96, false>), dim3(total), dim3(NT), 0, s, a); }
+  else                { if (dr) hipLaunchKernelGGL((attn_bwd_dq2_kernel<64, true>), dim3(total), dim3(NT), 0, s, a);
+                        else    hipLaunchKernelGGL((attn_bwd_dq2_kernel<64, false>), dim3(total), dim3(NT), 0, s, a); }
+  MMF_CHECK_LAUNCH("mmf_attn_bwd_grouped(dq, v2)");
+  total = fill_args2(a, problems, n, scale, drop_p, rng_state, site, 128, true, false);        // then dK/dV (reads delta)
+  if (head_dim == 96) { if (dr) hipLaunchKernelGGL((attn_bwd_dkv2_kernel<96, true>), dim3(total), dim3(NT), 0, s, a);
+                        else    hipLaunchKernelGGL((attn_bwd_dkv2_kernel<96, false>), dim3(total), dim3(NT), 0, s, a); }
+  else                { if (dr) hipLaunchKernelGGL((attn_bwd_dkv2_kernel<64, true>), dim3(total), dim3(NT), 0, s, a);
+                        else    hipLaunchKernelGGL((attn_bwd_dkv2_kernel<64, false>), dim3(total), dim3(NT), 0, s, a); }
+  MMF_CHECK_LAUNCH("mmf_attn_bwd_grouped(dkv, v2)");
+  return MMF_OK;
+}
+
+// Called by mmf_attn_fwd_grouped_ex (attention.hip) after validation when the second generation is selected.
+int mmf_attn_fwd2_launch(const mmf_attn_problem* problems, int n, int head_dim, float scale, float drop_p,
+                         const uint64_t* rng_state, uint32_t site, hipStream_t s) {
+  if (int rc = check_ranges("mmf_attn_fwd_grouped", problems, n)) return rc;
+  AttnArgs2 a;
+  const int total = fill_args2(a, problems, n, scale, drop_p, rng_state, site, 256, false, true);
   const bool dr = a.drop_thresh != 0u;
   if (head_dim == 96) { if (dr) hipLaunchKernelGGL((attn_fwd2_kernel<96, true>), dim3(total), dim3(NT), 0, s, a);
                         else    hipLaunchKernelGGL((attn_fwd2_kernel<96, false>), dim3(total), dim3(NT), 0, s, a); }

@@ -137,8 +137,8 @@ _LAYOUT_NAME = {GEMM_NT: "NT", GEMM_NN: "NN", GEMM_TN: "TN"}
 
 
 class _Timed:
-    def __init__(self, label: str, flops: float):
-        self.label, self.flops = label, flops
+    def __init__(self, label: str, flops: float, detail=None):
+        self.label, self.flops, self.detail = label, flops, detail
 
     def __enter__(self):
         if PROFILE is not None:
@@ -151,14 +151,15 @@ class _Timed:
         if PROFILE is not None:
             import torch
             self.e1.record(torch.cuda.current_stream())
-            PROFILE.append((self.label, self.flops, self.e0, self.e1))
+            PROFILE.append((self.label, self.flops, self.e0, self.e1, self.detail))
 
 
 def gemm_grouped(problems: Sequence[GemmProblem], layout: int, epilogue: int, out_f32: bool,
                  alpha: float = 1.0, dropout_p: float = 0.0, rng_state_ptr: Optional[int] = None, site: int = 0) -> None:
     arr = (GemmProblem * len(problems))(*problems)
     flops = sum(2.0 * p.M * p.N * p.K for p in problems) if PROFILE is not None else 0.0
-    with _Timed(f"gemm_grouped_kernel<{_LAYOUT_NAME[layout]},{'f32' if out_f32 else 'bf16'}>", flops):
+    detail = [(p.M, p.N, p.K) for p in problems] if PROFILE is not None else None
+    with _Timed(f"gemm_grouped_kernel<{_LAYOUT_NAME[layout]},{'f32' if out_f32 else 'bf16'}>", flops, detail):
         if alpha == 1.0 and not (epilogue & EPI_DROPOUT):
             check(load().mmf_gemm_grouped(arr, len(problems), layout, epilogue, int(out_f32), stream_ptr()))
         else:
@@ -170,7 +171,7 @@ def attn_fwd_grouped(problems: Sequence[AttnProblem], head_dim: int, scale: floa
                      rng_state_ptr: Optional[int] = None, site: int = 0) -> None:
     arr = (AttnProblem * len(problems))(*problems)
     flops = sum(4.0 * p.B * p.H * p.Tq * p.Tk * head_dim for p in problems) if PROFILE is not None else 0.0
-    with _Timed(f"attn_fwd_kernel<{head_dim}>", flops):
+    with _Timed(f"attn_fwd_kernel<{head_dim}>", flops, [(p.Tq, p.Tk) for p in problems] if PROFILE is not None else None):
         check(load().mmf_attn_fwd_grouped_ex(arr, len(problems), head_dim, scale, dropout_p, rng_state_ptr, site,
                                              stream_ptr()))
 
@@ -180,7 +181,7 @@ def attn_bwd_grouped(problems: Sequence[AttnProblem], head_dim: int, scale: floa
     arr = (AttnProblem * len(problems))(*problems)
     # algorithmic backward work: 4 products of 2*Tq*Tk*dh (dV, dP, dQ, dK); the recomputed S is not credited
     flops = sum(8.0 * p.B * p.H * p.Tq * p.Tk * head_dim for p in problems) if PROFILE is not None else 0.0
-    with _Timed(f"attn_bwd_kernels<{head_dim}>", flops):
+    with _Timed(f"attn_bwd_kernels<{head_dim}>", flops, [(p.Tq, p.Tk) for p in problems] if PROFILE is not None else None):
         check(load().mmf_attn_bwd_grouped_ex(arr, len(problems), head_dim, scale, dropout_p, rng_state_ptr, site,
                                              stream_ptr()))
 
