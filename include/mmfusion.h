@@ -208,6 +208,9 @@ int mmf_layernorm_bwd_grouped(const mmf_ln_problem* problems, int num_problems, 
 /* dst_bf16[i] = bf16(src_f32[i]); n multiple of 8 not required */
 int mmf_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 int mmf_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream);
+/* dst_f32[i] = scale * f32(src_bf16[i]): the receive side of the bf16-compressed gradient all-reduce
+ * (mmfusion/dp.py: widen the summed wire buffer and divide by the world size in one pass) */
+int mmf_cast_bf16_to_f32_scaled(const void* src, float* dst, int64_t n, float scale, void* stream);
 /* y = a + b + c (bf16); models/fusion_layers.py:156-158.  c may be NULL (y = a + b). */
 int mmf_add3_bf16(const void* a, const void* b, const void* c, void* y, int64_t n, void* stream);
 /* y[b][j] = mean_t x[b][t][j]  (models/fusion_layers.py:166-168); x bf16 [B][T][d], y bf16 with
@@ -231,6 +234,62 @@ int mmf_dropout(const void* x, void* y, int64_t n, int is_f32, float p, const ui
                 uint32_t site, void* stream);
 /* relu backward on bf16: dx = dy * (y > 0) */
 int mmf_relu_bwd_bf16(const void* dy, const void* y, void* dx, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Small fused kernels of the (B, d)-row branches (csrc/small.hip).  f32 unless said otherwise; every buffer
+ * is caller-owned; parameter gradients (datt_*, dbias, dW2, db2, dW, db, demb) are ACCUMULATED into.
+ * ------------------------------------------------------------------------------------------ */
+/* Dense 3-node GAT layer = torch_geometric GATConv(heads, concat=False) on the directed 3-clique plus self
+ * loops, as GraphFusion uses it (models/fusion_layers.py:223-232, 267-282): h [B][3][heads][C] is the node
+ * features after the layer's linear map (an mmf_gemm / skinny launch);
+ *   e[i,j,h] = leaky_relu(<h[i,h],att_dst[h]> + <h[j,h],att_src[h]>, negative_slope); alpha = softmax_j(e)
+ *   (denominator + 1e-16, PyG), dropout(alpha, p); out[i] = mean_h sum_j alpha[i,j,h] h[j,h] + bias
+ * y = relu(out) if relu (bf16 [B][3][C], the next layer's GEMM operand); pooled (optional, bf16 [B][C]) = mean over
+ * the 3 nodes of y (global_mean_pool, :285-286).  alpha [B][3][3][heads] (before dropout) and sdots [B][2][3][heads]
+ * are saved for the backward, which takes dy (bf16 [B][3][C]) and/or dpooled (bf16 [B][C]). */
+typedef struct mmf_gat3_params {
+  int32_t B, heads, C, relu;
+  float negative_slope, dropout_p;
+  const uint64_t* rng_state;
+  uint32_t site;
+} mmf_gat3_params;
+int mmf_gat3_dense_fwd(const float* h, const float* att_src, const float* att_dst, const float* bias,
+                       void* y_bf16, void* pooled_bf16, float* alpha, float* sdots,
+                       const mmf_gat3_params* p, void* stream);
+int mmf_gat3_dense_bwd(const float* h, const float* att_src, const float* att_dst, const void* y_bf16,
+                       const float* alpha, const float* sdots, const void* dy_bf16, const void* dpooled_bf16,
+                       float* dh, float* datt_src, float* datt_dst, float* dbias,
+                       const mmf_gat3_params* p, void* stream);
+/* n_m = z_m / max(||z_m||, 1e-12) for three (B, D) projections and, if losses != NULL, the symmetric InfoNCE of
+ * the pairs (0,1) (0,2) (1,2): (CE(n_a n_b^T / T, arange) + CE(transposed, arange)) / 2 — ContrastiveFusion,
+ * models/fusion_layers.py:338-347, 361-375.  B <= 64 (per-rank batch), D a multiple of 4.  inv_norm [3][B] and
+ * lse [3][2][B] are saved for the backward; dn[m] / dloss[p] may be NULL (no gradient from that output). */
+int mmf_infonce_fwd(const float* const z[3], float* const n[3], float* inv_norm, float* losses, float* lse,
+                    int B, int D, float temperature, void* stream);
+int mmf_infonce_bwd(const float* const n[3], const float* inv_norm, const float* lse, const float* const dn[3],
+                    const float* const dloss[3], float* const dz[3], int B, int D, float temperature, void* stream);
+/* AdaptiveFusion's weighting (:436-443): aw = softmax(hp W2^T + b2) [B][3]; weighted (bf16 [B][d]) =
+ * sum_m attended[b][m][:] aw[b][m].  Backward: dweighted bf16, daw optional. */
+int mmf_adaptive_combine_fwd(const float* hp, const float* W2, const float* b2, const float* attended,
+                             float* aw, void* weighted_bf16, int B, int d, void* stream);
+int mmf_adaptive_combine_bwd(const float* hp, const float* W2, const float* attended, const float* aw,
+                             const void* dweighted_bf16, const float* daw, float* dattended, float* dhp,
+                             float* dW2, float* db2, int B, int d, void* stream);
+/* Narrow linear heads, 1 <= N <= 16 outputs, f32 masters (LateFusion :50-60, EmotionClassifier / valence /
+ * arousal / uncertainty heads models/multimodal_model.py:56-60,186-219): y = x W^T + b.  dx may be NULL. */
+int mmf_linear_narrow_fwd(const float* x, const float* W, const float* b, float* y, int M, int N, int K, void* stream);
+int mmf_linear_narrow_bwd(const float* x, const float* W, const float* dy, float* dx, float* dW, float* db,
+                          int M, int N, int K, void* stream);
+/* x[b][m][:] = feat_m[b][:] + emb[m][:] as bf16 rows (GraphFusion node stacking + type embedding, :255-264;
+ * emb == NULL: plain stacking, AdaptiveFusion :427-429).  feat_m rows are ldf floats apart (3d when the three
+ * are the thirds of one (B, 3d) buffer).  Backward: any of d0..d2, demb may be NULL; d_m rows ldd apart. */
+int mmf_stack3_embed_fwd(const float* f0, const float* f1, const float* f2, const float* emb, void* x_bf16,
+                         int B, int d, int ldf, void* stream);
+int mmf_stack3_embed_bwd(const void* dx_bf16, float* d0, float* d1, float* d2, float* demb, int B, int d, int ldd,
+                         void* stream);
+/* y[b][:] = x[b][:] * mask[b]: ModalityDropout's per-sample keep masks (models/encoders.py:289-321, no rescale);
+ * the same call on dy is the backward. */
+int mmf_rowmask_apply(const float* x, const float* mask, float* y, int B, int d, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Training-step tail on the flat arenas (reference recipe training/advanced_trainer.py:85-110,

@@ -32,17 +32,17 @@ void cast_f32_bf16_kernel(const float* __restrict__ src, unsigned short* __restr
 }
 
 __global__ __launch_bounds__(EW_THREADS)
-void cast_bf16_f32_kernel(const unsigned short* __restrict__ src, float* __restrict__ dst, int64_t n) {
+void cast_bf16_f32_kernel(const unsigned short* __restrict__ src, float* __restrict__ dst, int64_t n, const float scale) {
   const int64_t nvec = n >> 3;
   const int64_t stride = (int64_t)gridDim.x * EW_THREADS;
   for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < nvec; i += stride) {
     const u32x4_t w = *reinterpret_cast<const u32x4_t*>(src + i * 8);
-    *reinterpret_cast<f32x4_t*>(dst + i * 8) = f32x4_t{bf16lo(w[0]), bf16hi(w[0]), bf16lo(w[1]), bf16hi(w[1])};
-    *reinterpret_cast<f32x4_t*>(dst + i * 8 + 4) = f32x4_t{bf16lo(w[2]), bf16hi(w[2]), bf16lo(w[3]), bf16hi(w[3])};
+    *reinterpret_cast<f32x4_t*>(dst + i * 8) = f32x4_t{bf16lo(w[0]), bf16hi(w[0]), bf16lo(w[1]), bf16hi(w[1])} * scale;
+    *reinterpret_cast<f32x4_t*>(dst + i * 8 + 4) = f32x4_t{bf16lo(w[2]), bf16hi(w[2]), bf16lo(w[3]), bf16hi(w[3])} * scale;
   }
   if (blockIdx.x == 0) {
     const int64_t t = (nvec << 3) + threadIdx.x;
-    if (t < n) dst[t] = bf16_bits_to_f32(src[t]);
+    if (t < n) dst[t] = bf16_bits_to_f32(src[t]) * scale;
   }
 }
 
@@ -236,13 +236,16 @@ extern "C" int mmf_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void
   return MMF_OK;
 }
 
-extern "C" int mmf_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream) {
+extern "C" int mmf_cast_bf16_to_f32_scaled(const void* src, float* dst, int64_t n, float scale, void* stream) {
   if (n <= 0) return MMF_OK;
   EW_PTR_CHECK("mmf_cast_bf16_to_f32", src && dst && mmf_aligned16(src) && mmf_aligned16(dst));
   hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(ew_grid(n >> 3)), dim3(EW_THREADS), 0,
-                     static_cast<hipStream_t>(stream), static_cast<const unsigned short*>(src), dst, n);
+                     static_cast<hipStream_t>(stream), static_cast<const unsigned short*>(src), dst, n, scale);
   MMF_CHECK_LAUNCH("mmf_cast_bf16_to_f32");
   return MMF_OK;
+}
+extern "C" int mmf_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream) {
+  return mmf_cast_bf16_to_f32_scaled(src, dst, n, 1.f, stream);
 }
 
 extern "C" int mmf_add3_bf16(const void* a, const void* b, const void* c, void* y, int64_t n, void* stream) {

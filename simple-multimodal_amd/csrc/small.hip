@@ -1,0 +1,662 @@
+// Small fused kernels of the (B, d)-row fusion branches (B ~ 16 per rank): dense 3-node GAT layer, L2-normalise +
+// symmetric InfoNCE, adaptive softmax-weighted combination, narrow (N <= 16) linear heads, node stacking with
+// type embedding, per-sample modality masks.  Each replaces 10-40 torch glue launches of a few microseconds
+// (profiles/r01_hier_kernel_stats.csv: 364 torch launches, 1.14 ms per hier-seq step before these existed).
+// They are latency-bound: one 256-thread workgroup per sample (or one workgroup in all for the B x B InfoNCE),
+// f32 arithmetic, wave reductions + one LDS hop; parameter gradients are accumulated straight into the f32
+// gradient arena (atomics across samples, 16 adders per address).
+#include "mmf_internal.h"
+
+namespace {
+
+constexpr int SM_THREADS = 256;
+constexpr int SM_WAVES = SM_THREADS / 64;
+
+// Sum N per-thread partials over the workgroup; the totals land in red[0..N) (LDS, >= N floats) for every thread.
+template <int N>
+__device__ __forceinline__ void block_sum(float (&v)[N], float* red, float* scratch /* [SM_WAVES][N] */) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const float s = wave_sum(v[i]);
+    if (lane == 0) scratch[wave * N + i] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < N) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < SM_WAVES; ++w) s += scratch[w * N + threadIdx.x];
+    red[threadIdx.x] = s;
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ float bf16_at(const unsigned short* p, size_t i) { return bf16_bits_to_f32(p[i]); }
+
+// ================================================================================================
+// Dense 3-node GAT layer (PyG GATConv(heads=H, concat=False) on the directed 3-clique + self loops,
+// reference models/fusion_layers.py:267-282 through torch_geometric).
+//   s_src[j,h] = <h[j,h,:], att_src[h,:]>, s_dst[i,h] = <h[i,h,:], att_dst[h,:]>
+//   e[i,j,h] = leaky_relu(s_dst[i,h] + s_src[j,h], 0.2); alpha = softmax_j(e) (denominator + 1e-16); dropout(alpha)
+//   out[i,c] = mean_h sum_j alpha[i,j,h] h[j,h,c] + bias[c];  y = relu(out) (bf16);  pooled = mean_i y
+// ================================================================================================
+
+struct Gat3Args {
+  const float* h; const float* att_src; const float* att_dst; const float* bias;
+  unsigned short* y; unsigned short* pooled; float* alpha; float* sdots;
+  const unsigned short* dy; const unsigned short* dpool; float* dh; float* datt_src; float* datt_dst; float* dbias;
+  int B, H, C, relu;
+  float slope, inv_keep; unsigned drop_thresh, site; const unsigned long long* rng_state;
+};
+
+template <int H>
+__global__ __launch_bounds__(SM_THREADS)
+void gat3_fwd_kernel(const Gat3Args a) {
+  __shared__ float red[6 * H], scratch[SM_WAVES * 6 * H], alpha_s[9 * H];
+  const int b = blockIdx.x, C = a.C, tid = threadIdx.x;
+  const float* hb = a.h + (size_t)b * 3 * H * C;
+  float part[6 * H];                                      // [src|dst][j][h]
+#pragma unroll
+  for (int i = 0; i < 6 * H; ++i) part[i] = 0.f;
+  for (int c = tid; c < C; c += SM_THREADS) {
+#pragma unroll
+    for (int hh = 0; hh < H; ++hh) {
+      const float as = a.att_src[hh * C + c], ad = a.att_dst[hh * C + c];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const float v = hb[(j * H + hh) * C + c];
+        part[j * H + hh] += v * as;
+        part[3 * H + j * H + hh] += v * ad;
+      }
+    }
+  }
+  block_sum<6 * H>(part, red, scratch);
+  if (tid < 6 * H) a.sdots[(size_t)b * 6 * H + tid] = red[tid];
+  if (tid < 3 * H) {                                      // thread = (i, hh): softmax over the three sources j
+    const int i = tid / H, hh = tid % H;
+    float e[3], mx = -3.0e38f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const float z = red[3 * H + i * H + hh] + red[j * H + hh];
+      e[j] = z > 0.f ? z : z * a.slope;
+      mx = fmaxf(mx, e[j]);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { e[j] = __expf(e[j] - mx); sum += e[j]; }
+    const float inv = 1.f / (sum + 1e-16f);
+    const unsigned key = a.drop_thresh ? mmf_rng_key(*a.rng_state, a.site, (unsigned)b) : 0u;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const float al = e[j] * inv;
+      a.alpha[((size_t)b * 9 + i * 3 + j) * H + hh] = al;
+      float ad = al;
+      if (a.drop_thresh) ad = mmf_keep(key, (unsigned)((i * 3 + j) * H + hh), a.drop_thresh) ? al * a.inv_keep : 0.f;
+      alpha_s[(i * 3 + j) * H + hh] = ad;
+    }
+  }
+  __syncthreads();
+  const float invH = 1.f / H;
+  for (int c = tid; c < C; c += SM_THREADS) {
+    float hv[3 * H];
+#pragma unroll
+    for (int q = 0; q < 3 * H; ++q) hv[q] = hb[q * C + c];
+    float pool = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      float o = 0.f;
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int hh = 0; hh < H; ++hh) o += alpha_s[(i * 3 + j) * H + hh] * hv[j * H + hh];
+      o = o * invH + a.bias[c];
+      if (a.relu) o = fmaxf(o, 0.f);
+      a.y[((size_t)b * 3 + i) * C + c] = f32_to_bf16_bits(o);
+      pool += o;
+    }
+    if (a.pooled) a.pooled[(size_t)b * C + c] = f32_to_bf16_bits(pool * (1.f / 3.f));
+  }
+}
+
+template <int H>
+__global__ __launch_bounds__(SM_THREADS)
+void gat3_bwd_kernel(const Gat3Args a) {
+  __shared__ float red[9 * H], scratch[SM_WAVES * 9 * H], alpha_d[9 * H], dssrc[3 * H], dsdst[3 * H];
+  const int b = blockIdx.x, C = a.C, tid = threadIdx.x;
+  const float* hb = a.h + (size_t)b * 3 * H * C;
+  const float invH = 1.f / H;
+  auto grad_out = [&](int i, int c) -> float {            // d(out[i,c]) through the pooling and the ReLU
+    float g = 0.f;
+    if (a.dy) g += bf16_at(a.dy, ((size_t)b * 3 + i) * C + c);
+    if (a.dpool) g += bf16_at(a.dpool, (size_t)b * C + c) * (1.f / 3.f);
+    if (a.relu && !(bf16_at(a.y, ((size_t)b * 3 + i) * C + c) > 0.f)) g = 0.f;
+    return g;
+  };
+  float part[9 * H];                                      // d(alpha_dropped)[i][j][h] = sum_c g[i,c]/H * h[j,h,c]
+#pragma unroll
+  for (int q = 0; q < 9 * H; ++q) part[q] = 0.f;
+  for (int c = tid; c < C; c += SM_THREADS) {
+    float g[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) g[i] = grad_out(i, c) * invH;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int hh = 0; hh < H; ++hh) {
+        const float v = hb[(j * H + hh) * C + c];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) part[(i * 3 + j) * H + hh] += g[i] * v;
+      }
+  }
+  block_sum<9 * H>(part, red, scratch);
+  if (tid < 3 * H) {                                      // thread = (i, hh): dropout, softmax and leaky-relu backward
+    const int i = tid / H, hh = tid % H;
+    const unsigned key = a.drop_thresh ? mmf_rng_key(*a.rng_state, a.site, (unsigned)b) : 0u;
+    const float* sd = a.sdots + (size_t)b * 6 * H;
+    float al[3], dal[3], dot = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      al[j] = a.alpha[((size_t)b * 9 + i * 3 + j) * H + hh];
+      float keep = 1.f;
+      if (a.drop_thresh) keep = mmf_keep(key, (unsigned)((i * 3 + j) * H + hh), a.drop_thresh) ? a.inv_keep : 0.f;
+      alpha_d[(i * 3 + j) * H + hh] = al[j] * keep;
+      dal[j] = red[(i * 3 + j) * H + hh] * keep;
+      dot += al[j] * dal[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const float z = sd[3 * H + i * H + hh] + sd[j * H + hh];
+      const float dz = al[j] * (dal[j] - dot) * (z > 0.f ? 1.f : a.slope);
+      red[(i * 3 + j) * H + hh] = dz;                     // own slots only: no other thread reads them before the barrier
+    }
+  }
+  __syncthreads();
+  if (tid < 3 * H) {                                      // thread = (node, hh)
+    const int n = tid / H, hh = tid % H;
+    float s = 0.f, d = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { s += red[(k * 3 + n) * H + hh]; d += red[(n * 3 + k) * H + hh]; }
+    dssrc[n * H + hh] = s;                                // d s_src[j = n]: sum over destinations i
+    dsdst[n * H + hh] = d;                                // d s_dst[i = n]: sum over sources j
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += SM_THREADS) {
+    float g[3], gb = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { const float go = grad_out(i, c); gb += go; g[i] = go * invH; }
+    atomicAdd(a.dbias + c, gb);
+#pragma unroll
+    for (int hh = 0; hh < H; ++hh) {
+      const float as = a.att_src[hh * C + c], ad = a.att_dst[hh * C + c];
+      float das = 0.f, dad = 0.f;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const float v = hb[(j * H + hh) * C + c];
+        float dv = dssrc[j * H + hh] * as + dsdst[j * H + hh] * ad;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) dv += alpha_d[(i * 3 + j) * H + hh] * g[i];
+        a.dh[((size_t)b * 3 * H + j * H + hh) * C + c] = dv;
+        das += dssrc[j * H + hh] * v;
+        dad += dsdst[j * H + hh] * v;
+      }
+      atomicAdd(a.datt_src + hh * C + c, das);
+      atomicAdd(a.datt_dst + hh * C + c, dad);
+    }
+  }
+}
+
+// ================================================================================================
+// L2-normalise three (B, D) projections and the symmetric InfoNCE of the three pairs (reference
+// models/fusion_layers.py:338-347, 361-375): one workgroup, B <= 64 (per-rank batch; sims live in LDS).
+//   n_m = z_m / max(||z_m||, 1e-12); sim_p = n_a n_b^T / T; loss_p = (CE(sim_p, arange) + CE(sim_p^T, arange)) / 2
+// pairs p: (0,1) (0,2) (1,2)
+// ================================================================================================
+constexpr int NCE_MAXB = 64;
+struct NceArgs {
+  const float* z[3]; float* n[3]; float* inv_norm;        // inv_norm [3][B]
+  float* losses;                                          // [3], may be NULL (normalise only)
+  float* lse;                                             // [3][2][B] row / column log-sum-exp, saved for backward
+  const float* dn[3];                                     // backward: grads w.r.t. the normalised outputs (may be NULL)
+  const float* dloss[3];                                  // backward: device scalars (may be NULL)
+  float* dz[3];
+  int B, D; float inv_temp;
+};
+
+__device__ __forceinline__ void nce_pair(int p, int& ma, int& mb) { ma = p == 2 ? 1 : 0; mb = p == 0 ? 1 : 2; }
+
+__global__ __launch_bounds__(SM_THREADS)
+void nce_fwd_kernel(const NceArgs a) {
+  extern __shared__ float sim[];                          // [3][B][B]
+  __shared__ float lsum[3];
+  const int B = a.B, D = a.D, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int r = wave; r < 3 * B; r += SM_WAVES) {          // one wave per row: norm, then the normalised row
+    const int m = r / B, i = r % B;
+    const float* z = a.z[m] + (size_t)i * D;
+    float ss = 0.f;
+    for (int c = lane; c < D; c += 64) ss += z[c] * z[c];
+    ss = wave_sum(ss);
+    const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+    if (lane == 0) a.inv_norm[r] = inv;
+    float* n = a.n[m] + (size_t)i * D;
+    for (int c = lane; c < D; c += 64) n[c] = z[c] * inv;
+  }
+  if (!a.losses) return;
+  __threadfence_block();
+  __syncthreads();
+  if (tid < 3) lsum[tid] = 0.f;
+  for (int e = tid; e < 3 * B * B; e += SM_THREADS) {     // sim[p][i][j]
+    const int p = e / (B * B), i = (e / B) % B, j = e % B;
+    int ma, mb; nce_pair(p, ma, mb);
+    const float* x = a.n[ma] + (size_t)i * D;
+    const float* y = a.n[mb] + (size_t)j * D;
+    float s = 0.f;
+    for (int c = 0; c < D; c += 4) {
+      const f32x4_t u = *reinterpret_cast<const f32x4_t*>(x + c), v = *reinterpret_cast<const f32x4_t*>(y + c);
+      s += u[0] * v[0] + u[1] * v[1] + u[2] * v[2] + u[3] * v[3];
+    }
+    sim[e] = s * a.inv_temp;
+  }
+  __syncthreads();
+  for (int t = tid; t < 3 * 2 * B; t += SM_THREADS) {     // (p, row|col, i): log-sum-exp and the diagonal term
+    const int p = t / (2 * B), col = (t / B) & 1, i = t % B;
+    const float* s = sim + p * B * B;
+    float mx = -3.0e38f;
+    for (int j = 0; j < B; ++j) mx = fmaxf(mx, col ? s[j * B + i] : s[i * B + j]);
+    float sum = 0.f;
+    for (int j = 0; j < B; ++j) sum += __expf((col ? s[j * B + i] : s[i * B + j]) - mx);
+    const float lse = mx + __logf(sum);
+    a.lse[t] = lse;
+    atomicAdd(&lsum[p], (lse - s[i * B + i]) * (0.5f / B));
+  }
+  __syncthreads();
+  if (tid < 3) a.losses[tid] = lsum[tid];
+}
+
+__global__ __launch_bounds__(SM_THREADS)
+void nce_bwd_kernel(const NceArgs a) {
+  extern __shared__ float dsim[];                         // [3][B][B]: d loss / d (n_a . n_b), 1/T included
+  const int B = a.B, D = a.D, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int e = tid; e < 3 * B * B; e += SM_THREADS) {
+    const int p = e / (B * B), i = (e / B) % B, j = e % B;
+    float g = 0.f;
+    if (a.dloss[p]) {
+      int ma, mb; nce_pair(p, ma, mb);
+      const float* x = a.n[ma] + (size_t)i * D;
+      const float* y = a.n[mb] + (size_t)j * D;
+      float s = 0.f;
+      for (int c = 0; c < D; c += 4) {
+        const f32x4_t u = *reinterpret_cast<const f32x4_t*>(x + c), v = *reinterpret_cast<const f32x4_t*>(y + c);
+        s += u[0] * v[0] + u[1] * v[1] + u[2] * v[2] + u[3] * v[3];
+      }
+      s *= a.inv_temp;
+      const float pr = __expf(s - a.lse[(p * 2 + 0) * B + i]), pc = __expf(s - a.lse[(p * 2 + 1) * B + j]);
+      g = *a.dloss[p] * (0.5f / B) * (pr + pc - (i == j ? 2.f : 0.f)) * a.inv_temp;
+    }
+    dsim[e] = g;
+  }
+  __syncthreads();
+  for (int r = wave; r < 3 * B; r += SM_WAVES) {          // one wave per row of dz_m
+    const int m = r / B, i = r % B;
+    const float* n = a.n[m] + (size_t)i * D;
+    const float inv = a.inv_norm[r];
+    float dot = 0.f;
+    // pairs that contain modality m: as first member (rows of dsim) or second member (columns)
+    for (int c = lane; c < D; c += 64) {
+      float g = a.dn[m] ? a.dn[m][(size_t)i * D + c] : 0.f;
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        int ma, mb; nce_pair(p, ma, mb);
+        if (ma == m) { const float* o = a.n[mb]; for (int j = 0; j < B; ++j) g += dsim[(p * B + i) * B + j] * o[(size_t)j * D + c]; }
+        if (mb == m) { const float* o = a.n[ma]; for (int j = 0; j < B; ++j) g += dsim[(p * B + j) * B + i] * o[(size_t)j * D + c]; }
+      }
+      a.dz[m][(size_t)i * D + c] = g;                     // dn for now; projected below
+      dot += g * n[c];
+    }
+    dot = wave_sum(dot);
+    for (int c = lane; c < D; c += 64) {                  // same lane wrote the element it now reads
+      const float g = a.dz[m][(size_t)i * D + c];
+      a.dz[m][(size_t)i * D + c] = (g - n[c] * dot) * inv;
+    }
+  }
+}
+
+// ================================================================================================
+// Adaptive combination (reference models/fusion_layers.py:436-443): aw = softmax(hp W2^T + b2) over the three
+// modalities, weighted = sum_m attended[:, m, :] aw[:, m]; one workgroup per sample.
+// ================================================================================================
+struct AdaArgs {
+  const float* hp; const float* W2; const float* b2; const float* attended;
+  float* aw; unsigned short* weighted;
+  const unsigned short* dweighted; const float* daw_ext; float* dattended; float* dhp; float* dW2; float* db2;
+  int B, d;
+};
+
+__global__ __launch_bounds__(SM_THREADS)
+void ada_fwd_kernel(const AdaArgs a) {
+  __shared__ float red[3], scratch[SM_WAVES * 3], aw_s[3];
+  const int b = blockIdx.x, d = a.d, tid = threadIdx.x;
+  float part[3] = {0.f, 0.f, 0.f};
+  for (int c = tid; c < d; c += SM_THREADS) {
+    const float x = a.hp[(size_t)b * d + c];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) part[m] += x * a.W2[m * d + c];
+  }
+  block_sum<3>(part, red, scratch);
+  if (tid == 0) {
+    float l[3], mx = -3.0e38f, s = 0.f;
+#pragma unroll
+    for (int m = 0; m < 3; ++m) { l[m] = red[m] + a.b2[m]; mx = fmaxf(mx, l[m]); }
+#pragma unroll
+    for (int m = 0; m < 3; ++m) { l[m] = __expf(l[m] - mx); s += l[m]; }
+#pragma unroll
+    for (int m = 0; m < 3; ++m) { aw_s[m] = l[m] / s; a.aw[b * 3 + m] = aw_s[m]; }
+  }
+  __syncthreads();
+  for (int c = tid; c < d; c += SM_THREADS) {
+    float w = 0.f;
+#pragma unroll
+    for (int m = 0; m < 3; ++m) w += a.attended[((size_t)b * 3 + m) * d + c] * aw_s[m];
+    a.weighted[(size_t)b * d + c] = f32_to_bf16_bits(w);
+  }
+}
+
+__global__ __launch_bounds__(SM_THREADS)
+void ada_bwd_kernel(const AdaArgs a) {
+  __shared__ float red[3], scratch[SM_WAVES * 3], dl_s[3];
+  const int b = blockIdx.x, d = a.d, tid = threadIdx.x;
+  float aw[3];
+#pragma unroll
+  for (int m = 0; m < 3; ++m) aw[m] = a.aw[b * 3 + m];
+  float part[3] = {0.f, 0.f, 0.f};
+  for (int c = tid; c < d; c += SM_THREADS) {
+    const float g = a.dweighted ? bf16_at(a.dweighted, (size_t)b * d + c) : 0.f;
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      part[m] += g * a.attended[((size_t)b * 3 + m) * d + c];
+      a.dattended[((size_t)b * 3 + m) * d + c] = g * aw[m];
+    }
+  }
+  block_sum<3>(part, red, scratch);
+  if (tid == 0) {
+    float da[3], dot = 0.f;
+#pragma unroll
+    for (int m = 0; m < 3; ++m) { da[m] = red[m] + (a.daw_ext ? a.daw_ext[b * 3 + m] : 0.f); dot += aw[m] * da[m]; }
+#pragma unroll
+    for (int m = 0; m < 3; ++m) { dl_s[m] = aw[m] * (da[m] - dot); atomicAdd(a.db2 + m, dl_s[m]); }
+  }
+  __syncthreads();
+  for (int c = tid; c < d; c += SM_THREADS) {
+    const float x = a.hp[(size_t)b * d + c];
+    float g = 0.f;
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      g += dl_s[m] * a.W2[m * d + c];
+      atomicAdd(a.dW2 + m * d + c, dl_s[m] * x);
+    }
+    a.dhp[(size_t)b * d + c] = g;
+  }
+}
+
+// ================================================================================================
+// Narrow linear heads, N <= 16 outputs (LateFusion's three d -> 7 classifiers :50-60, EmotionClassifier's last
+// layer and the valence / arousal / uncertainty heads, models/multimodal_model.py:56-60,186-219), f32 in / f32
+// master weights / f32 out: y[m][n] = sum_k x[m][k] W[n][k] + b[n]
+// ================================================================================================
+constexpr int NARROW_MAXN = 16;
+struct NarrowArgs {
+  const float* x; const float* W; const float* b; float* y;
+  const float* dy; float* dx; float* dW; float* db;
+  int M, N, K;
+};
+
+__global__ __launch_bounds__(SM_THREADS)
+void narrow_fwd_kernel(const NarrowArgs a) {
+  __shared__ float red[NARROW_MAXN], scratch[SM_WAVES * NARROW_MAXN];
+  const int m = blockIdx.x, K = a.K, N = a.N, tid = threadIdx.x;
+  float part[NARROW_MAXN];
+#pragma unroll
+  for (int n = 0; n < NARROW_MAXN; ++n) part[n] = 0.f;
+  for (int k = tid; k < K; k += SM_THREADS) {
+    const float x = a.x[(size_t)m * K + k];
+#pragma unroll
+    for (int n = 0; n < NARROW_MAXN; ++n)
+      if (n < N) part[n] += x * a.W[(size_t)n * K + k];
+  }
+  block_sum<NARROW_MAXN>(part, red, scratch);
+  if (tid < N) a.y[(size_t)m * N + tid] = red[tid] + (a.b ? a.b[tid] : 0.f);
+}
+
+// thread = one input column k (for every row m and output n): dx[m][k], dW[n][k] += ..., block 0 also db[n]
+__global__ __launch_bounds__(SM_THREADS)
+void narrow_bwd_kernel(const NarrowArgs a) {
+  const int k = blockIdx.x * SM_THREADS + threadIdx.x, K = a.K, N = a.N, M = a.M;
+  if (blockIdx.x == 0 && threadIdx.x < N && a.db) {
+    float s = 0.f;
+    for (int m = 0; m < M; ++m) s += a.dy[(size_t)m * N + threadIdx.x];
+    a.db[threadIdx.x] += s;
+  }
+  if (k >= K) return;
+  float w[NARROW_MAXN], dw[NARROW_MAXN];
+#pragma unroll
+  for (int n = 0; n < NARROW_MAXN; ++n) { w[n] = n < N ? a.W[(size_t)n * K + k] : 0.f; dw[n] = 0.f; }
+  for (int m = 0; m < M; ++m) {
+    const float x = a.x[(size_t)m * K + k];
+    float g = 0.f;
+#pragma unroll
+    for (int n = 0; n < NARROW_MAXN; ++n)
+      if (n < N) { const float d = a.dy[(size_t)m * N + n]; g += d * w[n]; dw[n] += d * x; }
+    if (a.dx) a.dx[(size_t)m * K + k] = g;
+  }
+#pragma unroll
+  for (int n = 0; n < NARROW_MAXN; ++n)
+    if (n < N) a.dW[(size_t)n * K + k] += dw[n];
+}
+
+// ================================================================================================
+// Node stacking + type embedding (reference :255-264): x[b][m][:] = feat_m[b][:] + emb[m][:]  -> bf16 rows
+// backward: dfeat_m[b][:] = dx[b][m][:], demb[m][:] += sum_b dx[b][m][:]
+// ================================================================================================
+__global__ __launch_bounds__(SM_THREADS)
+void stack3_fwd_kernel(const float* f0, const float* f1, const float* f2, const float* emb, unsigned short* x, int B, int d, int ldf) {
+  const int64_t n = (int64_t)B * 3 * d;
+  for (int64_t e = (int64_t)blockIdx.x * SM_THREADS + threadIdx.x; e < n; e += (int64_t)gridDim.x * SM_THREADS) {
+    const int c = (int)(e % d), m = (int)((e / d) % 3), b = (int)(e / (3 * (int64_t)d));
+    const float* f = m == 0 ? f0 : (m == 1 ? f1 : f2);
+    x[e] = f32_to_bf16_bits(f[(size_t)b * ldf + c] + (emb ? emb[m * d + c] : 0.f));
+  }
+}
+__global__ __launch_bounds__(SM_THREADS)
+void stack3_bwd_kernel(const unsigned short* dx, float* d0, float* d1, float* d2, float* demb, int B, int d, int ldd) {
+  const int e = blockIdx.x * SM_THREADS + threadIdx.x;     // (m, c)
+  if (e >= 3 * d) return;
+  const int m = e / d, c = e % d;
+  float* dst = m == 0 ? d0 : (m == 1 ? d1 : d2);
+  float s = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float g = bf16_at(dx, ((size_t)b * 3 + m) * d + c);
+    if (dst) dst[(size_t)b * ldd + c] = g;
+    s += g;
+  }
+  if (demb) demb[e] += s;
+}
+
+// y[b][:] = x[b][:] * mask[b]   (ModalityDropout keep-masks, models/encoders.py:289-321: no 1/(1-p) rescale)
+__global__ __launch_bounds__(SM_THREADS)
+void rowmask_kernel(const float* x, const float* mask, float* y, int B, int d) {
+  const int64_t n = (int64_t)B * d;
+  for (int64_t e = (int64_t)blockIdx.x * SM_THREADS + threadIdx.x; e < n; e += (int64_t)gridDim.x * SM_THREADS)
+    y[e] = x[e] * mask[e / d];
+}
+
+template <typename F>
+int dispatch_heads(int H, F&& f) {
+  switch (H) {
+    case 1: f(std::integral_constant<int, 1>{}); return MMF_OK;
+    case 2: f(std::integral_constant<int, 2>{}); return MMF_OK;
+    case 4: f(std::integral_constant<int, 4>{}); return MMF_OK;
+    case 8: f(std::integral_constant<int, 8>{}); return MMF_OK;
+  }
+  MMF_FAIL(MMF_E_UNSUPPORTED, "mmf_gat3_dense: heads=%d (supported: 1, 2, 4, 8)", H);
+}
+
+int fill_gat(Gat3Args& a, const mmf_gat3_params* p) {
+  if (!p || p->B <= 0 || p->C <= 0) MMF_FAIL(MMF_E_SHAPE, "mmf_gat3_dense: B=%d C=%d", p ? p->B : 0, p ? p->C : 0);
+  if (!(p->dropout_p >= 0.f) || p->dropout_p >= 1.f || (p->dropout_p > 0.f && !p->rng_state))
+    MMF_FAIL(MMF_E_SHAPE, "mmf_gat3_dense: dropout needs 0 <= p < 1 and an rng_state");
+  a.B = p->B; a.H = p->heads; a.C = p->C; a.relu = p->relu; a.slope = p->negative_slope;
+  a.drop_thresh = p->dropout_p > 0.f ? mmf_drop_thresh(p->dropout_p) : 0u;
+  a.inv_keep = a.drop_thresh ? 1.f / (1.f - (float)a.drop_thresh * (1.f / 4294967296.f)) : 1.f;
+  a.site = p->site;
+  a.rng_state = reinterpret_cast<const unsigned long long*>(p->rng_state);
+  return MMF_OK;
+}
+
+}  // namespace
+
+extern "C" int mmf_gat3_dense_fwd(const float* h, const float* att_src, const float* att_dst, const float* bias,
+                                  void* y_bf16, void* pooled_bf16, float* alpha, float* sdots,
+                                  const mmf_gat3_params* p, void* stream) {
+  Gat3Args a = {};
+  if (int rc = fill_gat(a, p)) return rc;
+  if (!h || !att_src || !att_dst || !bias || !y_bf16 || !alpha || !sdots) MMF_FAIL(MMF_E_SHAPE, "mmf_gat3_dense_fwd: null operand");
+  a.h = h; a.att_src = att_src; a.att_dst = att_dst; a.bias = bias;
+  a.y = static_cast<unsigned short*>(y_bf16); a.pooled = static_cast<unsigned short*>(pooled_bf16);
+  a.alpha = alpha; a.sdots = sdots;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (int rc = dispatch_heads(a.H, [&](auto Hc) {
+        hipLaunchKernelGGL((gat3_fwd_kernel<decltype(Hc)::value>), dim3(a.B), dim3(SM_THREADS), 0, s, a); })) return rc;
+  MMF_CHECK_LAUNCH("mmf_gat3_dense_fwd");
+  return MMF_OK;
+}
+
+extern "C" int mmf_gat3_dense_bwd(const float* h, const float* att_src, const float* att_dst, const void* y_bf16,
+                                  const float* alpha, const float* sdots, const void* dy_bf16, const void* dpooled_bf16,
+                                  float* dh, float* datt_src, float* datt_dst, float* dbias,
+                                  const mmf_gat3_params* p, void* stream) {
+  Gat3Args a = {};
+  if (int rc = fill_gat(a, p)) return rc;
+  if (!h || !att_src || !att_dst || !y_bf16 || !alpha || !sdots || !dh || !datt_src || !datt_dst || !dbias || (!dy_bf16 && !dpooled_bf16))
+    MMF_FAIL(MMF_E_SHAPE, "mmf_gat3_dense_bwd: null operand");
+  a.h = h; a.att_src = att_src; a.att_dst = att_dst;
+  a.y = const_cast<unsigned short*>(static_cast<const unsigned short*>(y_bf16));
+  a.alpha = const_cast<float*>(alpha); a.sdots = const_cast<float*>(sdots);
+  a.dy = static_cast<const unsigned short*>(dy_bf16); a.dpool = static_cast<const unsigned short*>(dpooled_bf16);
+  a.dh = dh; a.datt_src = datt_src; a.datt_dst = datt_dst; a.dbias = dbias;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (int rc = dispatch_heads(a.H, [&](auto Hc) {
+        hipLaunchKernelGGL((gat3_bwd_kernel<decltype(Hc)::value>), dim3(a.B), dim3(SM_THREADS), 0, s, a); })) return rc;
+  MMF_CHECK_LAUNCH("mmf_gat3_dense_bwd");
+  return MMF_OK;
+}
+
+static int nce_fill(NceArgs& a, const char* who, int B, int D, float temperature) {
+  if (B <= 0 || B > NCE_MAXB || D <= 0 || (D & 3)) MMF_FAIL(MMF_E_UNSUPPORTED, "%s: B=%d (1..%d) D=%d (multiple of 4)", who, B, NCE_MAXB, D);
+  if (!(temperature > 0.f)) MMF_FAIL(MMF_E_SHAPE, "%s: temperature must be positive", who);
+  a.B = B; a.D = D; a.inv_temp = 1.f / temperature;
+  return MMF_OK;
+}
+
+extern "C" int mmf_infonce_fwd(const float* const z[3], float* const n[3], float* inv_norm, float* losses, float* lse,
+                               int B, int D, float temperature, void* stream) {
+  NceArgs a = {};
+  if (int rc = nce_fill(a, "mmf_infonce_fwd", B, D, temperature)) return rc;
+  for (int m = 0; m < 3; ++m) {
+    if (!z[m] || !n[m] || !mmf_aligned16(z[m]) || !mmf_aligned16(n[m])) MMF_FAIL(MMF_E_ALIGN, "mmf_infonce_fwd: null or misaligned operand");
+    a.z[m] = z[m]; a.n[m] = n[m];
+  }
+  if (!inv_norm || (losses && !lse)) MMF_FAIL(MMF_E_SHAPE, "mmf_infonce_fwd: null statistics buffer");
+  a.inv_norm = inv_norm; a.losses = losses; a.lse = lse;
+  hipLaunchKernelGGL(nce_fwd_kernel, dim3(1), dim3(SM_THREADS), 3 * B * B * sizeof(float), static_cast<hipStream_t>(stream), a);
+  MMF_CHECK_LAUNCH("mmf_infonce_fwd");
+  return MMF_OK;
+}
+
+extern "C" int mmf_infonce_bwd(const float* const n[3], const float* inv_norm, const float* lse, const float* const dn[3],
+                               const float* const dloss[3], float* const dz[3], int B, int D, float temperature, void* stream) {
+  NceArgs a = {};
+  if (int rc = nce_fill(a, "mmf_infonce_bwd", B, D, temperature)) return rc;
+  bool any_loss = false;
+  for (int m = 0; m < 3; ++m) {
+    if (!n[m] || !dz[m]) MMF_FAIL(MMF_E_SHAPE, "mmf_infonce_bwd: null operand");
+    a.n[m] = const_cast<float*>(n[m]); a.dn[m] = dn ? dn[m] : nullptr; a.dloss[m] = dloss ? dloss[m] : nullptr; a.dz[m] = dz[m];
+    any_loss = any_loss || a.dloss[m];
+  }
+  if (!inv_norm || (any_loss && !lse)) MMF_FAIL(MMF_E_SHAPE, "mmf_infonce_bwd: null statistics buffer");
+  a.inv_norm = const_cast<float*>(inv_norm); a.lse = const_cast<float*>(lse);
+  hipLaunchKernelGGL(nce_bwd_kernel, dim3(1), dim3(SM_THREADS), 3 * B * B * sizeof(float), static_cast<hipStream_t>(stream), a);
+  MMF_CHECK_LAUNCH("mmf_infonce_bwd");
+  return MMF_OK;
+}
+
+extern "C" int mmf_adaptive_combine_fwd(const float* hp, const float* W2, const float* b2, const float* attended,
+                                        float* aw, void* weighted_bf16, int B, int d, void* stream) {
+  if (!hp || !W2 || !b2 || !attended || !aw || !weighted_bf16 || B <= 0 || d <= 0) MMF_FAIL(MMF_E_SHAPE, "mmf_adaptive_combine_fwd: bad operand");
+  AdaArgs a = {};
+  a.hp = hp; a.W2 = W2; a.b2 = b2; a.attended = attended; a.aw = aw; a.weighted = static_cast<unsigned short*>(weighted_bf16);
+  a.B = B; a.d = d;
+  hipLaunchKernelGGL(ada_fwd_kernel, dim3(B), dim3(SM_THREADS), 0, static_cast<hipStream_t>(stream), a);
+  MMF_CHECK_LAUNCH("mmf_adaptive_combine_fwd");
+  return MMF_OK;
+}
+
+extern "C" int mmf_adaptive_combine_bwd(const float* hp, const float* W2, const float* attended, const float* aw,
+                                        const void* dweighted_bf16, const float* daw, float* dattended, float* dhp,
+                                        float* dW2, float* db2, int B, int d, void* stream) {
+  if (!hp || !W2 || !attended || !aw || !dattended || !dhp || !dW2 || !db2 || B <= 0 || d <= 0)
+    MMF_FAIL(MMF_E_SHAPE, "mmf_adaptive_combine_bwd: bad operand");
+  AdaArgs a = {};
+  a.hp = hp; a.W2 = W2; a.attended = attended; a.aw = const_cast<float*>(aw);
+  a.dweighted = static_cast<const unsigned short*>(dweighted_bf16); a.daw_ext = daw;
+  a.dattended = dattended; a.dhp = dhp; a.dW2 = dW2; a.db2 = db2; a.B = B; a.d = d;
+  hipLaunchKernelGGL(ada_bwd_kernel, dim3(B), dim3(SM_THREADS), 0, static_cast<hipStream_t>(stream), a);
+  MMF_CHECK_LAUNCH("mmf_adaptive_combine_bwd");
+  return MMF_OK;
+}
+
+extern "C" int mmf_linear_narrow_fwd(const float* x, const float* W, const float* b, float* y, int M, int N, int K, void* stream) {
+  if (!x || !W || !y || M <= 0 || K <= 0 || N <= 0 || N > NARROW_MAXN) MMF_FAIL(MMF_E_SHAPE, "mmf_linear_narrow_fwd: M=%d N=%d (1..%d) K=%d", M, N, NARROW_MAXN, K);
+  NarrowArgs a = {};
+  a.x = x; a.W = W; a.b = b; a.y = y; a.M = M; a.N = N; a.K = K;
+  hipLaunchKernelGGL(narrow_fwd_kernel, dim3(M), dim3(SM_THREADS), 0, static_cast<hipStream_t>(stream), a);
+  MMF_CHECK_LAUNCH("mmf_linear_narrow_fwd");
+  return MMF_OK;
+}
+
+extern "C" int mmf_linear_narrow_bwd(const float* x, const float* W, const float* dy, float* dx, float* dW, float* db,
+                                     int M, int N, int K, void* stream) {
+  if (!x || !W || !dy || !dW || M <= 0 || K <= 0 || N <= 0 || N > NARROW_MAXN) MMF_FAIL(MMF_E_SHAPE, "mmf_linear_narrow_bwd: M=%d N=%d (1..%d) K=%d", M, N, NARROW_MAXN, K);
+  NarrowArgs a = {};
+  a.x = x; a.W = W; a.dy = dy; a.dx = dx; a.dW = dW; a.db = db; a.M = M; a.N = N; a.K = K;
+  hipLaunchKernelGGL(narrow_bwd_kernel, dim3((K + SM_THREADS - 1) / SM_THREADS), dim3(SM_THREADS), 0, static_cast<hipStream_t>(stream), a);
+  MMF_CHECK_LAUNCH("mmf_linear_narrow_bwd");
+  return MMF_OK;
+}
+
+extern "C" int mmf_stack3_embed_fwd(const float* f0, const float* f1, const float* f2, const float* emb, void* x_bf16,
+                                    int B, int d, int ldf, void* stream) {
+  if (!f0 || !f1 || !f2 || !x_bf16 || B <= 0 || d <= 0 || ldf < d) MMF_FAIL(MMF_E_SHAPE, "mmf_stack3_embed_fwd: bad operand");
+  const int64_t n = (int64_t)B * 3 * d;
+  const int grid = (int)((n + SM_THREADS - 1) / SM_THREADS < 2048 ? (n + SM_THREADS - 1) / SM_THREADS : 2048);
+  hipLaunchKernelGGL(stack3_fwd_kernel, dim3(grid), dim3(SM_THREADS), 0, static_cast<hipStream_t>(stream), f0, f1, f2, emb,
+                     static_cast<unsigned short*>(x_bf16), B, d, ldf);
+  MMF_CHECK_LAUNCH("mmf_stack3_embed_fwd");
+  return MMF_OK;
+}
+
+extern "C" int mmf_stack3_embed_bwd(const void* dx_bf16, float* d0, float* d1, float* d2, float* demb, int B, int d, int ldd,
+                                    void* stream) {
+  if (!dx_bf16 || B <= 0 || d <= 0 || ldd < d) MMF_FAIL(MMF_E_SHAPE, "mmf_stack3_embed_bwd: bad operand");
+  hipLaunchKernelGGL(stack3_bwd_kernel, dim3((3 * d + SM_THREADS - 1) / SM_THREADS), dim3(SM_THREADS), 0,
+                     static_cast<hipStream_t>(stream), static_cast<const unsigned short*>(dx_bf16), d0, d1, d2, demb, B, d, ldd);
+  MMF_CHECK_LAUNCH("mmf_stack3_embed_bwd");
+  return MMF_OK;
+}
+
+extern "C" int mmf_rowmask_apply(const float* x, const float* mask, float* y, int B, int d, void* stream) {
+  if (!x || !mask || !y || B <= 0 || d <= 0) MMF_FAIL(MMF_E_SHAPE, "mmf_rowmask_apply: bad operand");
+  const int64_t n = (int64_t)B * d;
+  const int grid = (int)((n + SM_THREADS - 1) / SM_THREADS < 2048 ? (n + SM_THREADS - 1) / SM_THREADS : 2048);
+  hipLaunchKernelGGL(rowmask_kernel, dim3(grid), dim3(SM_THREADS), 0, static_cast<hipStream_t>(stream), x, mask, y, B, d);
+  MMF_CHECK_LAUNCH("mmf_rowmask_apply");
+  return MMF_OK;
+}

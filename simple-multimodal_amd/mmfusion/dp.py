@@ -78,12 +78,13 @@ def allreduce_grads(arena, group=None, bucket_bytes: int = DEFAULT_BUCKET_BYTES,
         L, st = lib.load(), lib.stream_ptr()
         lib.check(L.mmf_cast_f32_to_bf16(arena.grads.data_ptr(), wire.data_ptr(), wire.numel(), st))
         allreduce_flat(wire, group, False, bucket_bytes)
-        lib.check(L.mmf_cast_bf16_to_f32(wire.data_ptr(), arena.grads.data_ptr(), wire.numel(), lib.stream_ptr()))
+        lib.check(L.mmf_cast_bf16_to_f32_scaled(wire.data_ptr(), arena.grads.data_ptr(), wire.numel(), 1.0 / world,
+                                                lib.stream_ptr()))          # widen and average in one pass
     else:                                   # CPU (gloo tests): same arithmetic with torch casts
         wire.copy_(arena.grads)
         allreduce_flat(wire, group, False, bucket_bytes)
         arena.grads.copy_(wire)
-    arena.grads.mul_(1.0 / world)
+        arena.grads.mul_(1.0 / world)
 
 
 def broadcast_params(arena, src: int = 0, group=None) -> None:

@@ -24,9 +24,12 @@ SYMBOLS = (
     "mmf_version", "mmf_last_error", "mmf_device_cu_count", "mmf_gemm_grouped", "mmf_gemm_grouped_ex", "mmf_gemm_select_impl",
     "mmf_attn_fwd_grouped_ex", "mmf_attn_bwd_grouped_ex", "mmf_dropout", "mmf_attn_select_impl",
     "mmf_attn_fwd_grouped", "mmf_attn_bwd_grouped", "mmf_layernorm_fwd_grouped",
-    "mmf_layernorm_bwd_grouped", "mmf_layernorm_bwd_workspace_bytes", "mmf_cast_f32_to_bf16", "mmf_cast_bf16_to_f32", "mmf_add3_bf16",
+    "mmf_layernorm_bwd_grouped", "mmf_layernorm_bwd_workspace_bytes", "mmf_cast_f32_to_bf16", "mmf_cast_bf16_to_f32", "mmf_cast_bf16_to_f32_scaled", "mmf_add3_bf16",
     "mmf_meanpool_fwd", "mmf_meanpool_bwd", "mmf_colsum_bf16", "mmf_colsum_grouped", "mmf_relu_bwd_bf16",
     "mmf_sqnorm_f32", "mmf_adamw_step", "mmf_skinny_linear_fwd", "mmf_skinny_linear_dgrad",
+    "mmf_gat3_dense_fwd", "mmf_gat3_dense_bwd", "mmf_infonce_fwd", "mmf_infonce_bwd", "mmf_adaptive_combine_fwd",
+    "mmf_adaptive_combine_bwd", "mmf_linear_narrow_fwd", "mmf_linear_narrow_bwd", "mmf_stack3_embed_fwd",
+    "mmf_stack3_embed_bwd", "mmf_rowmask_apply",
 )
 
 
@@ -63,6 +66,11 @@ class SkinnyProblem(C.Structure):
 SKINNY_MAX_M, SKINNY_MAX_PROBLEMS = 64, 24
 
 
+class Gat3Params(C.Structure):
+    _fields_ = [("B", C.c_int32), ("heads", C.c_int32), ("C", C.c_int32), ("relu", C.c_int32),
+                ("negative_slope", C.c_float), ("dropout_p", C.c_float), ("rng_state", C.c_void_p), ("site", C.c_uint32)]
+
+
 class ColsumProblem(C.Structure):
     _fields_ = [("x", C.c_void_p), ("out", C.c_void_p), ("M", C.c_int32), ("N", C.c_int32), ("ldx", C.c_int32)]
 
@@ -97,6 +105,7 @@ def load() -> C.CDLL:
     lib.mmf_layernorm_bwd_workspace_bytes.restype = C.c_size_t
     lib.mmf_cast_f32_to_bf16.argtypes = [vp, vp, i64, vp]
     lib.mmf_cast_bf16_to_f32.argtypes = [vp, vp, i64, vp]
+    lib.mmf_cast_bf16_to_f32_scaled.argtypes = [vp, vp, i64, f32, vp]
     lib.mmf_add3_bf16.argtypes = [vp, vp, vp, vp, i64, vp]
     lib.mmf_meanpool_fwd.argtypes = [vp, vp, i32, i32, i32, i32, vp]
     lib.mmf_meanpool_bwd.argtypes = [vp, vp, i32, i32, i32, i32, vp]
@@ -106,6 +115,18 @@ def load() -> C.CDLL:
     lib.mmf_skinny_linear_fwd.argtypes = [C.POINTER(SkinnyProblem), i32, i32, i32, vp]
     lib.mmf_skinny_linear_dgrad.argtypes = [C.POINTER(SkinnyProblem), i32, i32, f32, i32, vp]
     lib.mmf_sqnorm_f32.argtypes = [vp, i64, vp, vp]
+    P3 = C.c_void_p * 3
+    lib.mmf_gat3_dense_fwd.argtypes = [vp] * 8 + [C.POINTER(Gat3Params), vp]
+    lib.mmf_gat3_dense_bwd.argtypes = [vp] * 12 + [C.POINTER(Gat3Params), vp]
+    lib.mmf_infonce_fwd.argtypes = [P3, P3, vp, vp, vp, i32, i32, f32, vp]
+    lib.mmf_infonce_bwd.argtypes = [P3, vp, vp, P3, P3, P3, i32, i32, f32, vp]
+    lib.mmf_adaptive_combine_fwd.argtypes = [vp] * 6 + [i32, i32, vp]
+    lib.mmf_adaptive_combine_bwd.argtypes = [vp] * 10 + [i32, i32, vp]
+    lib.mmf_linear_narrow_fwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp]
+    lib.mmf_linear_narrow_bwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]
+    lib.mmf_stack3_embed_fwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp]
+    lib.mmf_stack3_embed_bwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp]
+    lib.mmf_rowmask_apply.argtypes = [vp, vp, vp, i32, i32, vp]
     lib.mmf_adamw_step.argtypes = [vp, vp, vp, vp, vp, i64, vp, vp, vp]
     for name in SYMBOLS:
         getattr(lib, name)          # AttributeError here = header and .so disagree

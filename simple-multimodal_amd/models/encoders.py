@@ -187,9 +187,13 @@ class ModalityDropout(nn.Module):
             return text_features, audio_features, video_features
         B, dev = text_features.size(0), text_features.device
         keep = torch.rand(B, 3, device=dev) > self.dropout_rate
-        dropped = ~keep.any(dim=1)
-        if dropped.any():
-            choice = torch.randint(0, 3, (int(dropped.sum()),), device=dev)
-            keep[dropped] = torch.nn.functional.one_hot(choice, 3).bool()
+        # samples that lost all three modalities get one back at random (:308-314) — written without the
+        # reference's data-dependent branch so that nothing synchronises with the host (hipGraph-capturable)
+        choice = torch.nn.functional.one_hot(torch.randint(0, 3, (B,), device=dev), 3).bool()
+        keep = torch.where(keep.any(dim=1, keepdim=True), keep, choice)
         k = keep.float()
+        if text_features.is_cuda and text_features.dim() == 2:
+            from mmfusion import small_ops as sops               # y[b, :] = x[b, :] * keep[b, m]: HIP kernel
+            return (sops.rowmask(text_features, k[:, 0].contiguous()), sops.rowmask(audio_features, k[:, 1].contiguous()),
+                    sops.rowmask(video_features, k[:, 2].contiguous()))
         return text_features * k[:, 0:1], audio_features * k[:, 1:2], video_features * k[:, 2:3]

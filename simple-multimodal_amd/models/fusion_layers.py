@@ -27,6 +27,7 @@ import torch.nn.functional as F
 
 from mmfusion import arena as _arena
 from mmfusion import ops
+from mmfusion import small_ops as sops
 from mmfusion.ops import AttnSpec, LinearSpec, W
 
 _depth = 0          # >0 while inside an outer fusion forward: the arena was already ensured
@@ -47,6 +48,7 @@ class _FusionBase(nn.Module):
         global _depth
         _depth -= 1
         if _depth == 0:
+            _cat3_memo.clear()
             arena = getattr(next(self.parameters(), None), "_mmf_arena", None)
             if arena is not None:
                 arena.join()            # side-stream cast / zeroing never outlives the root forward
@@ -72,6 +74,24 @@ def _as_rows(x: torch.Tensor) -> torch.Tensor:
     if not x.is_cuda:
         raise RuntimeError("mmfusion fusion layers run on the GPU only (no CPU fallback)")
     return ops.to_bf16(x.contiguous()).reshape(-1, x.shape[-1])
+
+
+_cat3_memo: Dict[tuple, Tuple[torch.Tensor, torch.Tensor]] = {}
+
+
+def _cat3(t: torch.Tensor, a: torch.Tensor, v: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(fp32 (B, 3d), bf16 (B, 3d)) of cat([t, a, v], -1), computed once per root forward: Early, Contrastive,
+    Adaptive and Graph fusion all start from the same concatenation (reference :36, :350, :436, :255-264)."""
+    if not t.is_cuda:
+        raise RuntimeError("mmfusion fusion layers run on the GPU only (no CPU fallback)")
+    key = (t.data_ptr(), a.data_ptr(), v.data_ptr(), t._version, a._version, v._version, tuple(t.shape))
+    hit = _cat3_memo.get(key)
+    if hit is None:
+        c32 = sops.cat3(t, a, v)
+        hit = (c32, ops.to_bf16(c32))
+        if _depth > 0:                    # the memo lives for one root forward (cleared in _FusionBase._exit)
+            _cat3_memo[key] = hit
+    return hit
 
 
 def _lin(layer: nn.Linear, relu: bool = False) -> LinearSpec:
@@ -162,7 +182,7 @@ class EarlyFusion(_FusionBase):
 
     def forward(self, text_features, audio_features, video_features) -> torch.Tensor:
         p = _p(self, self.config.fusion_dropout)
-        x = _as_rows(torch.cat([text_features, audio_features, video_features], dim=-1))
+        _, x = _cat3(text_features, audio_features, video_features)                    # bf16 (B, 3d), :36
         h = ops.dropout(ops.linear(x, *_wb(self.fusion_layers[0]), relu=True), p, True)
         return ops.dropout(ops.linear(h, *_wb(self.fusion_layers[3]), relu=True, out_f32=True), p, True)
 
@@ -172,8 +192,8 @@ def _wb(layer: nn.Linear):
 
 
 # ------------------------------------------------------------------------------------------------
-# a5  LateFusion  (reference :46-90) — three d->7 heads + a 3-way softmax: kept on torch (N = 7 is
-# below the kernels' 4-column granularity and the arithmetic is ~10 kFLOP/sample)
+# a5  LateFusion  (reference :46-90) — three d->7 heads through the narrow-linear kernel (f32 masters, exact);
+# the softmax over the three learned fusion weights and the weighted logit sum are three scalars of torch glue
 # ------------------------------------------------------------------------------------------------
 class LateFusion(_FusionBase):
     def __init__(self, config):
@@ -186,10 +206,12 @@ class LateFusion(_FusionBase):
         self.fusion_weights = nn.Parameter(torch.ones(3) / 3)
 
     def forward(self, text_features, audio_features, video_features) -> Dict[str, torch.Tensor]:
-        tl = F.linear(text_features.float(), self.text_classifier.weight, self.text_classifier.bias)
-        al = F.linear(audio_features.float(), self.audio_classifier.weight, self.audio_classifier.bias)
-        vl = F.linear(video_features.float(), self.video_classifier.weight, self.video_classifier.bias)
-        w = F.softmax(self.fusion_weights, dim=0)
+        if not text_features.is_cuda:
+            raise RuntimeError("mmfusion fusion layers run on the GPU only (no CPU fallback)")
+        tl = sops.narrow_linear(text_features, self.text_classifier)             # d -> num_emotions heads: HIP
+        al = sops.narrow_linear(audio_features, self.audio_classifier)
+        vl = sops.narrow_linear(video_features, self.video_classifier)
+        w = F.softmax(self.fusion_weights, dim=0)                                  # three scalars
         return {"fused_logits": w[0] * tl + w[1] * al + w[2] * vl, "text_logits": tl,
                 "audio_logits": al, "video_logits": vl, "fusion_weights": w}
 
@@ -291,19 +313,12 @@ class _DenseGAT(nn.Module):
                 state_dict.setdefault(prefix + "lin.weight", w)
         super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
-    def forward(self, x: torch.Tensor, B: int, p: float = 0.0) -> torch.Tensor:
-        """x: bf16 (B*3, in) -> fp32 (B, 3, out), ReLU not included.  p: GATConv's dropout on alpha."""
-        Hh, C = self.heads, self.out_channels
-        h = ops.linear(x, W(self.lin.weight), None, out_f32=True).view(B, 3, Hh, C)   # MFMA GEMM
-        # 3x3 additive attention per (sample, head): ~100 FLOP — torch glue
-        s_src = (h * self.att_src).sum(-1)
-        s_dst = (h * self.att_dst).sum(-1)
-        e = F.leaky_relu(s_dst.unsqueeze(2) + s_src.unsqueeze(1), 0.2)                 # (B,i,j,H)
-        ex = torch.exp(e - e.max(dim=2, keepdim=True).values)
-        alpha = ex / (ex.sum(dim=2, keepdim=True) + 1e-16)
-        if p > 0.0:
-            alpha = F.dropout(alpha, p, True)           # (B,3,3,4) coefficients: torch RNG, plumbing-sized
-        return torch.einsum("bijh,bjhc->bihc", alpha, h).mean(dim=2) + self.bias
+    def forward(self, x: torch.Tensor, B: int, p: float = 0.0, pool: bool = False):
+        """x: bf16 (B*3, in) -> relu(GATConv(x)) as bf16 (B*3, out) rows; with ``pool`` also the mean over the three
+        nodes, bf16 (B, out).  The linear map is an MFMA GEMM, everything else one fused kernel (csrc/small.hip
+        gat3_*: scores, leaky-relu, 3-way softmax, dropout on alpha with p, aggregation, head mean, bias, ReLU)."""
+        h = ops.linear(x, W(self.lin.weight), None, out_f32=True)                      # (B*3, heads*out) f32
+        return sops.gat3(h, self.att_src, self.att_dst, self.bias, B, self.heads, relu=True, pool=pool, dropout_p=p)
 
 
 class GraphFusion(_FusionBase):
@@ -321,13 +336,16 @@ class GraphFusion(_FusionBase):
 
     def forward(self, text_features, audio_features, video_features) -> torch.Tensor:
         B = text_features.shape[0]
-        x = torch.stack([text_features.float(), audio_features.float(), video_features.float()], dim=1)
-        x = x + self.node_type_embedding.weight                                        # :255-264
+        c32, _ = _cat3(text_features, audio_features, video_features)
+        x = sops.stack3_embed(c32, self.node_type_embedding.weight)                    # :255-264, bf16 (B*3, d)
         pg = _p(self, self.config.graph_dropout)
-        for layer in self.gcn_layers:                                                  # :280-282
-            x = torch.relu(layer(_as_rows(x), B, pg))
-        pooled = x.mean(dim=1)                                                         # :285-286
-        return ops.linear(_as_rows(pooled), *_wb(self.output_projection), out_f32=True)
+        pooled = None
+        for l, layer in enumerate(self.gcn_layers):                                    # :280-282
+            if l + 1 < len(self.gcn_layers):
+                x = layer(x, B, pg)
+            else:
+                x, pooled = layer(x, B, pg, pool=True)                                 # :285-286 mean over the nodes
+        return ops.linear(pooled, *_wb(self.output_projection), out_f32=True)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -346,17 +364,25 @@ class ContrastiveFusion(_FusionBase):
     def forward(self, text_features, audio_features, video_features,
                 compute_contrastive_loss: bool = False) -> Dict[str, torch.Tensor]:
         p = _p(self, self.config.fusion_dropout)
-        xs = [_as_rows(text_features), _as_rows(audio_features), _as_rows(video_features)]
+        d = text_features.shape[-1]
+        _, cat = _cat3(text_features, audio_features, video_features)                  # bf16 (B, 3d)
+        xs = [cat[:, i * d:(i + 1) * d] for i in range(3)]
         projs = [self.text_projector, self.audio_projector, self.video_projector]
         h = ops.linear_group([(x, _lin(p[0], relu=True), None) for x, p in zip(xs, projs)])
         z = ops.linear_group([(hh, _lin(p[2]), None) for hh, p in zip(h, projs)], out_f32=True)
-        tp, ap, vp = (F.normalize(t, dim=-1) for t in z)                               # :338-340
         losses = {}
-        if compute_contrastive_loss:                                                   # :344-347
-            losses = {"text_audio": self.contrastive_loss(tp, ap),
-                      "text_video": self.contrastive_loss(tp, vp),
-                      "audio_video": self.contrastive_loss(ap, vp)}
-        cat = _as_rows(torch.cat([text_features, audio_features, video_features], dim=-1))
+        if text_features.shape[0] <= sops.NCE_MAX_B:
+            # :338-347, 361-375: L2-normalise the three projections and the three symmetric InfoNCE losses in ONE
+            # kernel (csrc/small.hip nce_*); the per-rank batch is small, the B x B similarities live in LDS
+            (tp, ap, vp), ls = sops.normalize_infonce(z, self.temperature, compute_contrastive_loss)
+            if compute_contrastive_loss:
+                losses = {"text_audio": ls[0], "text_video": ls[1], "audio_video": ls[2]}
+        else:                                   # B > 64 per rank: the B x B InfoNCE on torch ops (GPU)
+            tp, ap, vp = (F.normalize(t, dim=-1) for t in z)
+            if compute_contrastive_loss:
+                losses = {"text_audio": self.contrastive_loss(tp, ap),
+                          "text_video": self.contrastive_loss(tp, vp),
+                          "audio_video": self.contrastive_loss(ap, vp)}
         fused = ops.dropout(ops.linear(cat, *_wb(self.fusion_layer[0]), relu=True, out_f32=True), p, True)
         return {"fused_features": fused, "text_proj": tp, "audio_proj": ap, "video_proj": vp,
                 "contrastive_losses": losses}
@@ -388,7 +414,8 @@ class AdaptiveFusion(_FusionBase):
         B, d = text_features.shape
         mp = self.attention
         H, dh = mp.num_heads, mp.head_dim
-        xs = [_as_rows(text_features), _as_rows(audio_features), _as_rows(video_features)]
+        _, cat = _cat3(text_features, audio_features, video_features)                  # bf16 (B, 3d)
+        xs = [cat[:, i * d:(i + 1) * d] for i in range(3)]
         tr = ops.linear_group([(x, _lin(l), None) for x, l in
                                zip(xs, (self.text_transform, self.audio_transform, self.video_transform))])
         stacked = torch.stack(tr, dim=1).reshape(B * 3, d)                             # (B,3,d) :427-429
@@ -399,11 +426,10 @@ class AdaptiveFusion(_FusionBase):
             q4 = qkv.detach().float().view(B, 3, 3, H, dh)
             sc = torch.einsum("bihd,bjhd->bhij", q4[:, :, 0], q4[:, :, 1]) / math.sqrt(dh)
             attn_w = F.softmax(sc, dim=-1).mean(dim=1)
-        cat = _as_rows(torch.cat([text_features, audio_features, video_features], dim=-1))
         hp = ops.linear(cat, *_wb(self.weight_predictor[0]), relu=True, out_f32=True)
-        aw = F.softmax(F.linear(hp, self.weight_predictor[2].weight, self.weight_predictor[2].bias), dim=-1)
-        weighted = (attended * aw.unsqueeze(-1)).sum(dim=1)                            # :441-443
-        fused = ops.dropout(ops.linear(_as_rows(weighted), *_wb(self.fusion_layer[0]), relu=True, out_f32=True), p, True)
+        # :436-443: d -> 3 logits, softmax, weighted sum of the attended modalities — one kernel (small.hip ada_*)
+        weighted, aw = sops.adaptive_combine(hp, attended, self.weight_predictor[2].weight, self.weight_predictor[2].bias)
+        fused = ops.dropout(ops.linear(weighted, *_wb(self.fusion_layer[0]), relu=True, out_f32=True), p, True)
         return {"fused_features": fused, "attention_weights": attn_w, "adaptive_weights": aw}
 
 

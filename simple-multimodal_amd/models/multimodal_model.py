@@ -4,9 +4,9 @@ Kept verbatim: constructor ``(config)``, ``forward(text_input, audio_input, vide
 use_adapter, use_prompt, compute_contrastive_loss, missing_modalities) -> Dict`` and its output
 keys (reference :159-181), ``fusion_type`` dispatch incl. the ``ValueError`` (:29-46),
 ``EmotionClassifier`` (:186-219), ``create_model`` / ``load_pretrained_model`` (:453-485) and all
-``state_dict`` names.  The fusion layer and the encoder tails are the MI355X HIP path; the
-7-class / 1-unit heads (classifier, valence, arousal, uncertainty) are a few kFLOP per sample and
-stay on torch (their output width is below the GEMM kernel's 4-column granularity).
+``state_dict`` names.  The fusion layer, the encoder tails and the heads are the MI355X HIP path: the
+classifier's d -> d/2 layer on the skinny MFMA kernel, the 7-class / 1-unit output layers (classifier, valence,
+arousal, uncertainty) on the narrow-linear kernel (f32 masters); the softmaxes over 7 logits are torch glue.
 
 Research wrappers (``KnowledgeDistillationModel``, ``FewShotModel``, ``RobustMultimodalModel``,
 reference :222-450) are outside the hot path: the names exist so that
@@ -19,6 +19,10 @@ from typing import Dict, List, Optional
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+from mmfusion import ops
+from mmfusion import small_ops as sops
+from mmfusion.ops import W
 
 from .encoders import AudioEncoder, ModalityDropout, TextEncoder, VideoEncoder
 from .fusion_layers import (AdaptiveFusion, ContrastiveFusion, EarlyFusion, GraphFusion,
@@ -43,7 +47,17 @@ class EmotionClassifier(nn.Module):
         self.negative_classifier = nn.Linear(d, 4)
 
     def forward(self, features: torch.Tensor) -> torch.Tensor:
-        return self.classifier(features)
+        """d -> d/2 (ReLU, dropout) on the skinny MFMA kernel, d/2 -> num_emotions on the narrow-linear kernel."""
+        if not features.is_cuda:
+            raise RuntimeError("mmfusion: the classifier head runs on the GPU only (no CPU fallback)")
+        from mmfusion import arena as _arena_mod
+        if getattr(self.classifier[0].weight, "_mmf_arena", None) is None:
+            _arena_mod.ensure(self)                # stand-alone use; inside MultimodalEmotionModel the root did it
+        p = float(self.config.fusion_dropout) if self.training else 0.0
+        x = ops.to_bf16(features.float().contiguous())
+        l0 = self.classifier[0]
+        h = ops.dropout(ops.linear(x, W(l0.weight), W(l0.bias), relu=True, out_f32=True), p, True)
+        return sops.narrow_linear(h, self.classifier[3])
 
 
 class MultimodalEmotionModel(_FusionBase):
@@ -98,8 +112,9 @@ class MultimodalEmotionModel(_FusionBase):
             head_in = fo["fused_features"] if isinstance(fo, dict) else fo
             emotion_logits = self.classifier(head_in)
         out = {"emotion_logits": emotion_logits, "emotion_probs": F.softmax(emotion_logits, dim=-1),
-               "valence": self.valence_regressor(head_in), "arousal": self.arousal_regressor(head_in),
-               "uncertainty": F.softmax(self.uncertainty_head(head_in), dim=-1),
+               "valence": sops.narrow_linear(head_in, self.valence_regressor),
+               "arousal": sops.narrow_linear(head_in, self.arousal_regressor),
+               "uncertainty": F.softmax(sops.narrow_linear(head_in, self.uncertainty_head), dim=-1),
                "text_features": tf, "audio_features": af, "video_features": vf}
         if self.fusion_type == "late":
             out.update({"individual_logits": individual_logits, "fusion_weights": fusion_weights})

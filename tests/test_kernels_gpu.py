@@ -343,3 +343,146 @@ def test_lazy_zero_grad_is_bit_identical_and_zeroes_untouched_matrices():
     assert torch.equal(g_eager2, g_lazy2)
     proj = [p for n, p in m.named_parameters() if "projector" in n and p.dim() == 2]
     assert proj and all(float(p.grad.abs().max()) == 0.0 for p in proj)
+
+
+# ---- small fused branch kernels (csrc/small.hip) against plain torch fp32 references -----------------------
+def _small_param(*shape):
+    p = torch.nn.Parameter(torch.randn(*shape, device="cuda") * 0.3)
+    p.grad = torch.zeros_like(p)
+    return p
+
+
+def test_gat3_dense_matches_torch_dense_gat():
+    from mmfusion import small_ops as sops
+    torch.manual_seed(11)
+    B, H, C = 5, 4, 136
+    h = torch.randn(B * 3, H * C, device="cuda", requires_grad=True)
+    att_src, att_dst, bias = _small_param(1, H, C), _small_param(1, H, C), _small_param(C)
+    y, pooled = sops.gat3(h, att_src, att_dst, bias, B, H, relu=True, pool=True)
+    gy = torch.randn(B * 3, C, device="cuda").bfloat16()
+    gp = torch.randn(B, C, device="cuda").bfloat16()
+    torch.autograd.backward([y, pooled], [gy, gp])
+
+    h2 = h.detach().clone().requires_grad_(True)
+    ps = [p.detach().clone().requires_grad_(True) for p in (att_src, att_dst, bias)]
+    hv = h2.view(B, 3, H, C)
+    s_src, s_dst = (hv * ps[0]).sum(-1), (hv * ps[1]).sum(-1)
+    e = torch.nn.functional.leaky_relu(s_dst.unsqueeze(2) + s_src.unsqueeze(1), 0.2)
+    ex = torch.exp(e - e.max(dim=2, keepdim=True).values)
+    alpha = ex / (ex.sum(dim=2, keepdim=True) + 1e-16)
+    out = torch.relu(torch.einsum("bijh,bjhc->bihc", alpha, hv).mean(dim=2) + ps[2])
+    # the kernel applies the ReLU mask of its bf16-rounded output; do the same here
+    torch.autograd.backward([out, out.mean(dim=1)], [gy.float().view(B, 3, C), gp.float()])
+    out = out.detach()
+    assert (y.float().view(B, 3, C) - out).abs().max() <= 2 ** -7 * max(1.0, float(out.abs().max()))
+    assert (pooled.float() - out.mean(dim=1)).abs().max() <= 2 ** -7 * max(1.0, float(out.abs().max()))
+    for got, ref in ((h.grad, h2.grad), (att_src.grad, ps[0].grad), (att_dst.grad, ps[1].grad), (bias.grad, ps[2].grad)):
+        assert (got - ref).abs().max() <= 2e-3 * max(1.0, float(ref.abs().max())), float((got - ref).abs().max())
+
+
+def test_gat3_alpha_dropout_is_consistent_between_forward_and_backward():
+    """With dropout on alpha the mask is regenerated in the backward: d<y, g>/dh by finite differences of the
+    kernel itself (same step state => same mask) must match the analytic dh."""
+    from mmfusion import ops, small_ops as sops
+    torch.manual_seed(12)
+    B, H, C = 3, 4, 64
+    att_src, att_dst, bias = _small_param(1, H, C), _small_param(1, H, C), _small_param(C)
+    h = torch.randn(B * 3, H * C, device="cuda", requires_grad=True)
+    g = torch.randn(B * 3, C, device="cuda")
+
+    def run(hh):
+        ops._site = 0
+        return sops.gat3(hh, att_src, att_dst, bias, B, H, relu=False, pool=False, dropout_p=0.4)
+    y = run(h)
+    y.backward(g.bfloat16())
+    d = torch.randn_like(h) * 1e-2
+    with torch.no_grad():
+        fd = ((run(h + d).float() - run(h - d).float()) * g).sum() / 2
+    an = (h.grad * d).sum()
+    assert abs(float(fd - an)) <= 0.05 * max(1.0, abs(float(an))), (float(fd), float(an))
+
+
+def test_normalize_infonce_matches_torch():
+    import torch.nn.functional as Fn
+    from mmfusion import small_ops as sops
+    torch.manual_seed(13)
+    B, D, T = 16, 384, 0.07
+    zs = [torch.randn(B, D, device="cuda", requires_grad=True) for _ in range(3)]
+    ns, ls = sops.normalize_infonce(zs, T, True)
+    wl = torch.tensor([0.3, 1.1, 0.7], device="cuda")
+    gn = [torch.randn(B, D, device="cuda") * 0.01 for _ in range(3)]
+    (sum(w * l for w, l in zip(wl, ls)) + sum((n * g).sum() for n, g in zip(ns, gn))).backward()
+
+    z2 = [z.detach().clone().requires_grad_(True) for z in zs]
+    n2 = [Fn.normalize(z, dim=-1) for z in z2]
+    lab = torch.arange(B, device="cuda")
+
+    def nce(a, b):
+        sim = a @ b.t() / T
+        return (Fn.cross_entropy(sim, lab) + Fn.cross_entropy(sim.t(), lab)) / 2
+    l2 = [nce(n2[0], n2[1]), nce(n2[0], n2[2]), nce(n2[1], n2[2])]
+    (sum(w * l for w, l in zip(wl, l2)) + sum((n * g).sum() for n, g in zip(n2, gn))).backward()
+    for a, b in zip(ns, n2):
+        assert (a - b).abs().max() <= 1e-6
+    for a, b in zip(ls, l2):
+        assert abs(float(a - b)) <= 1e-4 * max(1.0, abs(float(b)))
+    for a, b in zip(zs, z2):
+        assert (a.grad - b.grad).abs().max() <= 1e-4 * max(1.0, float(b.grad.abs().max()))
+
+
+def test_adaptive_combine_and_narrow_linear_match_torch():
+    import torch.nn.functional as Fn
+    from mmfusion import small_ops as sops
+    torch.manual_seed(14)
+    B, d = 16, 200
+    hp = torch.randn(B, d, device="cuda", requires_grad=True)
+    att = torch.randn(B, 3, d, device="cuda", requires_grad=True)
+    w2, b2 = _small_param(3, d), _small_param(3)
+    weighted, aw = sops.adaptive_combine(hp, att, w2, b2)
+    gw, ga = torch.randn(B, d, device="cuda").bfloat16(), torch.randn(B, 3, device="cuda")
+    torch.autograd.backward([weighted, aw], [gw, ga])
+    hp2, att2 = hp.detach().clone().requires_grad_(True), att.detach().clone().requires_grad_(True)
+    w22, b22 = w2.detach().clone().requires_grad_(True), b2.detach().clone().requires_grad_(True)
+    aw2 = Fn.softmax(Fn.linear(hp2, w22, b22), dim=-1)
+    wt2 = (att2 * aw2.unsqueeze(-1)).sum(dim=1)
+    torch.autograd.backward([wt2, aw2], [gw.float(), ga])
+    assert (aw - aw2).abs().max() <= 1e-5
+    assert (weighted.float() - wt2).abs().max() <= 2 ** -7 * max(1.0, float(wt2.abs().max()))
+    for got, ref in ((hp.grad, hp2.grad), (att.grad, att2.grad), (w2.grad, w22.grad), (b2.grad, b22.grad)):
+        assert (got - ref).abs().max() <= 1e-4 * max(1.0, float(ref.abs().max()))
+
+    lin = torch.nn.Linear(d, 7).cuda()
+    lin.weight.grad, lin.bias.grad = torch.zeros_like(lin.weight), torch.zeros_like(lin.bias)
+    x = torch.randn(B, d, device="cuda", requires_grad=True)
+    y = sops.narrow_linear(x, lin)
+    gy = torch.randn(B, 7, device="cuda")
+    y.backward(gy)
+    x2 = x.detach().clone().requires_grad_(True)
+    wr, br = lin.weight.detach().clone().requires_grad_(True), lin.bias.detach().clone().requires_grad_(True)
+    y2 = Fn.linear(x2, wr, br)
+    y2.backward(gy)
+    assert (y - y2).abs().max() <= 1e-4
+    for got, ref in ((x.grad, x2.grad), (lin.weight.grad, wr.grad), (lin.bias.grad, br.grad)):
+        assert (got - ref).abs().max() <= 1e-4 * max(1.0, float(ref.abs().max()))
+
+
+def test_stack3_embed_and_rowmask():
+    from mmfusion import small_ops as sops
+    torch.manual_seed(15)
+    B, d = 6, 72
+    base = torch.randn(B, 3 * d, device="cuda", requires_grad=True)
+    t, a, v = base[:, :d], base[:, d:2 * d], base[:, 2 * d:]
+    assert sops.cat3(t, a, v) is base                          # thirds of one buffer: no copy
+    emb = _small_param(3, d)
+    x = sops.stack3_embed(sops.cat3(t, a, v), emb)
+    ref = (torch.stack([t, a, v], dim=1) + emb).reshape(B * 3, d)
+    assert (x.float() - ref).abs().max() <= 2 ** -7 * max(1.0, float(ref.abs().max()))
+    g = torch.randn(B * 3, d, device="cuda").bfloat16()
+    x.backward(g)
+    assert torch.equal(base.grad.view(B, 3, d), g.float().view(B, 3, d))
+    assert (emb.grad - g.float().view(B, 3, d).sum(0)).abs().max() <= 1e-5
+    xm = torch.randn(B, d, device="cuda", requires_grad=True)
+    m = (torch.rand(B, device="cuda") > 0.5).float()
+    ym = sops.rowmask(xm, m)
+    ym.backward(torch.ones_like(ym))
+    assert torch.equal(ym, xm.detach() * m[:, None]) and torch.equal(xm.grad, m[:, None].expand(B, d))
