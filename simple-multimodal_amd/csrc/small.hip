@@ -224,100 +224,100 @@ struct NceArgs {
 
 __device__ __forceinline__ void nce_pair(int p, int& ma, int& mb) { ma = p == 2 ? 1 : 0; mb = p == 0 ? 1 : 2; }
 
+// wave-wide dot product of two D-vectors (coalesced: lanes stride the columns)
+__device__ __forceinline__ float wave_dot(const float* __restrict__ x, const float* __restrict__ y, int D, int lane) {
+  float s = 0.f;
+  for (int c = lane * 4; c < D; c += 256) {
+    const f32x4_t u = *reinterpret_cast<const f32x4_t*>(x + c), v = *reinterpret_cast<const f32x4_t*>(y + c);
+    s += u[0] * v[0] + u[1] * v[1] + u[2] * v[2] + u[3] * v[3];
+  }
+  return wave_sum(s);
+}
+
+// forward: one workgroup per pair p.  It normalises the two modalities of its pair (each modality is normalised
+// by two workgroups, writing identical values), then one WAVE per (i, j) similarity, then the row / column
+// log-sum-exps and the loss.
 __global__ __launch_bounds__(SM_THREADS)
 void nce_fwd_kernel(const NceArgs a) {
-  extern __shared__ float sim[];                          // [3][B][B]
-  __shared__ float lsum[3];
-  const int B = a.B, D = a.D, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int r = wave; r < 3 * B; r += SM_WAVES) {          // one wave per row: norm, then the normalised row
-    const int m = r / B, i = r % B;
+  extern __shared__ float sim[];                          // [B][B]
+  __shared__ float lsum;
+  const int B = a.B, D = a.D, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p = blockIdx.x;
+  int ma, mb; nce_pair(p, ma, mb);
+  for (int r = wave; r < 2 * B; r += SM_WAVES) {          // one wave per row: norm, then the normalised row
+    const int m = r < B ? ma : mb, i = r < B ? r : r - B;
     const float* z = a.z[m] + (size_t)i * D;
     float ss = 0.f;
     for (int c = lane; c < D; c += 64) ss += z[c] * z[c];
     ss = wave_sum(ss);
     const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
-    if (lane == 0) a.inv_norm[r] = inv;
+    if (lane == 0) a.inv_norm[m * B + i] = inv;
     float* n = a.n[m] + (size_t)i * D;
     for (int c = lane; c < D; c += 64) n[c] = z[c] * inv;
   }
   if (!a.losses) return;
-  __threadfence_block();
-  __syncthreads();
-  if (tid < 3) lsum[tid] = 0.f;
-  for (int e = tid; e < 3 * B * B; e += SM_THREADS) {     // sim[p][i][j]
-    const int p = e / (B * B), i = (e / B) % B, j = e % B;
-    int ma, mb; nce_pair(p, ma, mb);
-    const float* x = a.n[ma] + (size_t)i * D;
-    const float* y = a.n[mb] + (size_t)j * D;
-    float s = 0.f;
-    for (int c = 0; c < D; c += 4) {
-      const f32x4_t u = *reinterpret_cast<const f32x4_t*>(x + c), v = *reinterpret_cast<const f32x4_t*>(y + c);
-      s += u[0] * v[0] + u[1] * v[1] + u[2] * v[2] + u[3] * v[3];
-    }
-    sim[e] = s * a.inv_temp;
+  if (tid == 0) lsum = 0.f;
+  __syncthreads();                                        // this workgroup's own writes of n are visible to it
+  for (int e = wave; e < B * B; e += SM_WAVES) {
+    const float s = wave_dot(a.n[ma] + (size_t)(e / B) * D, a.n[mb] + (size_t)(e % B) * D, D, lane);
+    if (lane == 0) sim[e] = s * a.inv_temp;
   }
   __syncthreads();
-  for (int t = tid; t < 3 * 2 * B; t += SM_THREADS) {     // (p, row|col, i): log-sum-exp and the diagonal term
-    const int p = t / (2 * B), col = (t / B) & 1, i = t % B;
-    const float* s = sim + p * B * B;
+  for (int t = tid; t < 2 * B; t += SM_THREADS) {         // (row | col, i): log-sum-exp and the diagonal term
+    const int col = t / B, i = t % B;
     float mx = -3.0e38f;
-    for (int j = 0; j < B; ++j) mx = fmaxf(mx, col ? s[j * B + i] : s[i * B + j]);
+    for (int j = 0; j < B; ++j) mx = fmaxf(mx, col ? sim[j * B + i] : sim[i * B + j]);
     float sum = 0.f;
-    for (int j = 0; j < B; ++j) sum += __expf((col ? s[j * B + i] : s[i * B + j]) - mx);
+    for (int j = 0; j < B; ++j) sum += __expf((col ? sim[j * B + i] : sim[i * B + j]) - mx);
     const float lse = mx + __logf(sum);
-    a.lse[t] = lse;
-    atomicAdd(&lsum[p], (lse - s[i * B + i]) * (0.5f / B));
+    a.lse[p * 2 * B + t] = lse;
+    atomicAdd(&lsum, (lse - sim[i * B + i]) * (0.5f / B));
   }
   __syncthreads();
-  if (tid < 3) a.losses[tid] = lsum[tid];
+  if (tid == 0) a.losses[p] = lsum;
 }
 
+// backward: workgroup (m, row block) computes dz_m for SM_WAVES rows.  It first rebuilds d loss / d sim of the
+// two pairs that contain modality m (one wave per similarity), then one wave per row: dn = dn_ext + sum over
+// the pairs of dsim . n_other (coalesced over the columns), and the projection of the normalisation.
 __global__ __launch_bounds__(SM_THREADS)
 void nce_bwd_kernel(const NceArgs a) {
-  extern __shared__ float dsim[];                         // [3][B][B]: d loss / d (n_a . n_b), 1/T included
-  const int B = a.B, D = a.D, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int e = tid; e < 3 * B * B; e += SM_THREADS) {
-    const int p = e / (B * B), i = (e / B) % B, j = e % B;
+  extern __shared__ float dsim[];                         // [2][B][B]: the two pairs of this modality, 1/T included
+  const int B = a.B, D = a.D, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = blockIdx.x;
+  int pairs[2], q = 0;
+  for (int p = 0; p < 3; ++p) { int ma, mb; nce_pair(p, ma, mb); if (ma == m || mb == m) pairs[q++] = p; }
+  for (int e = wave; e < 2 * B * B; e += SM_WAVES) {
+    const int p = pairs[e / (B * B)], i = (e / B) % B, j = e % B;
     float g = 0.f;
-    if (a.dloss[p]) {
+    if (a.dloss[p]) {                                     // wave-uniform
       int ma, mb; nce_pair(p, ma, mb);
-      const float* x = a.n[ma] + (size_t)i * D;
-      const float* y = a.n[mb] + (size_t)j * D;
-      float s = 0.f;
-      for (int c = 0; c < D; c += 4) {
-        const f32x4_t u = *reinterpret_cast<const f32x4_t*>(x + c), v = *reinterpret_cast<const f32x4_t*>(y + c);
-        s += u[0] * v[0] + u[1] * v[1] + u[2] * v[2] + u[3] * v[3];
-      }
-      s *= a.inv_temp;
+      const float s = wave_dot(a.n[ma] + (size_t)i * D, a.n[mb] + (size_t)j * D, D, lane) * a.inv_temp;
       const float pr = __expf(s - a.lse[(p * 2 + 0) * B + i]), pc = __expf(s - a.lse[(p * 2 + 1) * B + j]);
       g = *a.dloss[p] * (0.5f / B) * (pr + pc - (i == j ? 2.f : 0.f)) * a.inv_temp;
     }
-    dsim[e] = g;
+    if (lane == 0) dsim[e] = g;
   }
   __syncthreads();
-  for (int r = wave; r < 3 * B; r += SM_WAVES) {          // one wave per row of dz_m
-    const int m = r / B, i = r % B;
-    const float* n = a.n[m] + (size_t)i * D;
-    const float inv = a.inv_norm[r];
-    float dot = 0.f;
-    // pairs that contain modality m: as first member (rows of dsim) or second member (columns)
-    for (int c = lane; c < D; c += 64) {
-      float g = a.dn[m] ? a.dn[m][(size_t)i * D + c] : 0.f;
+  const int i = blockIdx.y * SM_WAVES + wave;
+  if (i >= B) return;
+  const float* n = a.n[m] + (size_t)i * D;
+  float* dz = a.dz[m] + (size_t)i * D;
+  float dot = 0.f;
+  for (int c = lane; c < D; c += 64) {
+    float g = a.dn[m] ? a.dn[m][(size_t)i * D + c] : 0.f;
 #pragma unroll
-      for (int p = 0; p < 3; ++p) {
-        int ma, mb; nce_pair(p, ma, mb);
-        if (ma == m) { const float* o = a.n[mb]; for (int j = 0; j < B; ++j) g += dsim[(p * B + i) * B + j] * o[(size_t)j * D + c]; }
-        if (mb == m) { const float* o = a.n[ma]; for (int j = 0; j < B; ++j) g += dsim[(p * B + j) * B + i] * o[(size_t)j * D + c]; }
-      }
-      a.dz[m][(size_t)i * D + c] = g;                     // dn for now; projected below
-      dot += g * n[c];
+    for (int k = 0; k < 2; ++k) {
+      int ma, mb; nce_pair(pairs[k], ma, mb);
+      const float* o = a.n[ma == m ? mb : ma];
+      const float* ds = dsim + k * B * B;
+      if (ma == m) { for (int j = 0; j < B; ++j) g += ds[i * B + j] * o[(size_t)j * D + c]; }
+      else         { for (int j = 0; j < B; ++j) g += ds[j * B + i] * o[(size_t)j * D + c]; }
     }
-    dot = wave_sum(dot);
-    for (int c = lane; c < D; c += 64) {                  // same lane wrote the element it now reads
-      const float g = a.dz[m][(size_t)i * D + c];
-      a.dz[m][(size_t)i * D + c] = (g - n[c] * dot) * inv;
-    }
+    dz[c] = g;                                            // dn for now; projected below (same lane re-reads it)
+    dot += g * n[c];
   }
+  dot = wave_sum(dot);
+  const float inv = a.inv_norm[m * B + i];
+  for (int c = lane; c < D; c += 64) dz[c] = (dz[c] - n[c] * dot) * inv;
 }
 
 // ================================================================================================
@@ -566,7 +566,7 @@ extern "C" int mmf_infonce_fwd(const float* const z[3], float* const n[3], float
   }
   if (!inv_norm || (losses && !lse)) MMF_FAIL(MMF_E_SHAPE, "mmf_infonce_fwd: null statistics buffer");
   a.inv_norm = inv_norm; a.losses = losses; a.lse = lse;
-  hipLaunchKernelGGL(nce_fwd_kernel, dim3(1), dim3(SM_THREADS), 3 * B * B * sizeof(float), static_cast<hipStream_t>(stream), a);
+  hipLaunchKernelGGL(nce_fwd_kernel, dim3(3), dim3(SM_THREADS), B * B * sizeof(float), static_cast<hipStream_t>(stream), a);
   MMF_CHECK_LAUNCH("mmf_infonce_fwd");
   return MMF_OK;
 }
@@ -583,7 +583,8 @@ extern "C" int mmf_infonce_bwd(const float* const n[3], const float* inv_norm, c
   }
   if (!inv_norm || (any_loss && !lse)) MMF_FAIL(MMF_E_SHAPE, "mmf_infonce_bwd: null statistics buffer");
   a.inv_norm = const_cast<float*>(inv_norm); a.lse = const_cast<float*>(lse);
-  hipLaunchKernelGGL(nce_bwd_kernel, dim3(1), dim3(SM_THREADS), 3 * B * B * sizeof(float), static_cast<hipStream_t>(stream), a);
+  hipLaunchKernelGGL(nce_bwd_kernel, dim3(3, (B + SM_WAVES - 1) / SM_WAVES), dim3(SM_THREADS), 2 * B * B * sizeof(float),
+                     static_cast<hipStream_t>(stream), a);
   MMF_CHECK_LAUNCH("mmf_infonce_bwd");
   return MMF_OK;
 }
