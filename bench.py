@@ -179,27 +179,39 @@ def cpu_baseline(workload):
                       f"steps ({best:.2f} s/step) on {model_name}"}
 
 
-_SYMBOL = {"gemm_grouped_kernel<NT,bf16>": "gemm2_grouped_kernel<false, false, false>",
-           "gemm_grouped_kernel<NT,f32>": "gemm2_grouped_kernel<false, false, true>",
-           "gemm_grouped_kernel<NN,bf16>": "gemm2_grouped_kernel<false, true, false>",
-           "gemm_grouped_kernel<TN,f32>": "gemm2_grouped_kernel<true, true, true>",
-           "attn_fwd_kernel<96>": "attn_fwd_kernel<96>"}
+_SYMBOL = {"gemm_grouped_kernel<NT,bf16>": ["gemm4_grouped_kernel<false, false, false>", "gemm2_grouped_kernel<false, false, false>"],
+           "gemm_grouped_kernel<NT,f32>": ["gemm2_grouped_kernel<false, false, true>"],
+           "gemm_grouped_kernel<NN,bf16>": ["gemm4_grouped_kernel<false, true, false>", "gemm2_grouped_kernel<false, true, false>"],
+           "gemm_grouped_kernel<TN,f32>": ["gemm2_grouped_kernel<true, true, true>"],
+           "attn_fwd_kernel<96>": ["attn_fwd2_kernel<96, false>"],
+           "attn_bwd_kernels<96>": ["attn_bwd_dq2_kernel<96, false>", "attn_bwd_dkv2_kernel<96, false>"]}
 
 
-def pmc_traffic(label):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes
-    (profiles/*_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of this
-    same workload, FETCH_SIZE x2 for gfx950).  bench.py cannot profile itself, hence the file; None if absent."""
+def pmc_lookup(label):
+    """(HBM bytes per launch, MFMA utilisation) of a bench kernel label from the committed PMC passes
+    (profiles/*_pmc_traffic.json, written by tools/pmc_summary.py from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE /
+    SQ_VALU_MFMA_BUSY_CYCLES runs of this same workload, FETCH_SIZE x2 for gfx950).  bench.py cannot profile
+    itself, hence the file; (None, None) if absent.  A label that covers two kernel generations (NT/NN: 256x256
+    and 256x128 tiles) reports the launch-weighted mean; the two backward attention kernels are summed."""
     import glob
     files = sorted(glob.glob(os.path.join(REPO, "profiles", "*_pmc_traffic.json")))
     if not files or label not in _SYMBOL:
-        return None
+        return None, None
     try:
         with open(files[-1]) as f:
-            k = json.load(f)["kernels"].get(_SYMBOL[label])
-        return int(k["hbm_bytes_per_launch"]) if k else None
+            K = json.load(f)["kernels"]
+        hits = [K[s] for s in _SYMBOL[label] if s in K]
+        if not hits:
+            return None, None
+        if label.startswith("attn_bwd"):
+            return int(sum(h["hbm_bytes_per_launch"] for h in hits)), None
+        n = sum(h["launches"] for h in hits)
+        traffic = int(sum(h["hbm_bytes_per_launch"] * h["launches"] for h in hits) / n)
+        utils = [(h["mfma_util"], h["launches"]) for h in hits if "mfma_util" in h]
+        util = round(sum(u * c for u, c in utils) / sum(c for _, c in utils), 4) if utils else None
+        return traffic, util
     except (OSError, ValueError, KeyError):
-        return None
+        return None, None
 
 
 def kernel_profile(step, nsteps):
@@ -209,14 +221,18 @@ def kernel_profile(step, nsteps):
     for _ in range(nsteps):
         step()
     torch.cuda.synchronize()
+    from mmfusion import synth
+    S = synth.C2_SHAPES
     agg = {}
-    for label, flops, e0, e1, *_ in lib.PROFILE:
-        a = agg.setdefault(label, [0.0, 0.0, 0])
+    for label, flops, e0, e1, detail in lib.PROFILE:
+        a = agg.setdefault(label, [0.0, 0.0, 0, 0.0])
         a[0] += e0.elapsed_time(e1)
         a[1] += flops
         a[2] += 1
+        if label.startswith("attn_fwd") and detail:      # min HBM bytes of a core = bf16 Q, K, V in, O out
+            a[3] += sum(2.0 * (2 * tq + 2 * tk) * S["d"] * S["B"] for tq, tk in detail)
     lib.PROFILE = None
-    return {k: {"ms_total": v[0], "flops_total": v[1], "launches": v[2]} for k, v in agg.items()}
+    return {k: {"ms_total": v[0], "flops_total": v[1], "launches": v[2], "bytes_total": v[3]} for k, v in agg.items()}
 
 
 def main():
@@ -345,8 +361,10 @@ def main():
         dom = max(prof, key=lambda k: prof[k]["ms_total"])
         dsec = prof[dom]["ms_total"] * 1e-3
         ach = prof[dom]["flops_total"] / dsec / 1e12
+        traffic, mfma_util = pmc_lookup(dom)
         roofline = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": BF16_MFMA_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic(dom),
+                    "unit": "TFLOP/s", "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                    "mfma_util_pmc": mfma_util,
                     "avg_launch_us": round(prof[dom]["ms_total"] * 1e3 / prof[dom]["launches"], 2),
                     "launches_per_step": prof[dom]["launches"] // args.profile_steps}
         kernels = {k: {"us_per_step": round(v["ms_total"] * 1e3 / args.profile_steps, 1),
@@ -368,6 +386,21 @@ def main():
             "roofline": roofline,
             "kernels": kernels,
         }
+        af = prof.get("attn_fwd_kernel<96>")
+        if af and af["ms_total"] > 0:
+            # the north_star's named kernel: the MulT attention cores.  At these shapes the cores sit below the
+            # 312 FLOP/B ridge (123-256 FLOP/B), so both roofs are reported: algorithmic FLOPs vs the bf16 MFMA peak
+            # and algorithmic bytes (Q, K, V in, O out, once each) vs the HBM peak.
+            sec = af["ms_total"] * 1e-3
+            traffic, util = pmc_lookup("attn_fwd_kernel<96>")
+            line["roofline_attention_fwd"] = {
+                "kernel": "attn_fwd2_kernel<96> (all nine MulT attention cores, 2 launches)",
+                "mfma": {"achieved": round(af["flops_total"] / sec / 1e12, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(af["flops_total"] / sec / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4)},
+                "hbm": {"achieved": round(af["bytes_total"] / sec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(af["bytes_total"] / sec / 1e9 / HBM_PEAK_GBS, 4)},
+                "traffic": traffic, "mfma_util_pmc": util,
+                "avg_launch_us": round(af["ms_total"] * 1e3 / af["launches"], 2)}
         if world == 1 and not args.no_cpu_baseline and args.workload == "mult":
             line["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(line), flush=True)

@@ -87,6 +87,9 @@ def load() -> C.CDLL:
         raise RuntimeError(
             f"{LIB_PATH} is missing: the MI355X fusion path has no fallback. Build it with "
             f"`python -c 'import __graft_entry__ as g; g.build()'` or `make -C simple-multimodal_amd/csrc`.")
+    # torch first: its wheel bundles its own libamdhip64; libmmfusion.so must bind to THAT copy (same SONAME), or the
+    # process ends up with two HIP runtimes and this library's launches fail with "no ROCm-capable device"
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     lib.mmf_last_error.restype = C.c_char_p
     lib.mmf_version.restype = C.c_int
