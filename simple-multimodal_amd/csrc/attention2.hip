@@ -208,7 +208,7 @@ __device__ __forceinline__ void fwd2_wave(const AttnArgs2& a, const mmf_attn_pro
           float mx = s[qb][0];
 #pragma unroll
           for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[qb][r]);
-          mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * c;
+          mx = half_max(mx) * c;
           if (!__all(mx <= m[qb] + DEFER)) {               // wave-uniform: raise the running maximum
             const float mnew = fmaxf(m[qb], mx);
             const float alpha = fast_exp2(m[qb] - mnew);
@@ -251,7 +251,7 @@ __device__ __forceinline__ void fwd2_wave(const AttnArgs2& a, const mmf_attn_pro
     unsigned short* Og = static_cast<unsigned short*>(P.O) + (size_t)b * Tq * P.ldo + h * DH;
 #pragma unroll
     for (int qb = 0; qb < NQ; ++qb) {
-      const float lt = l[qb] + __shfl_xor(l[qb], 32, 64);
+      const float lt = half_sum(l[qb]);
       store_rows_lds<DH>(o[qb], 1.f / lt, Og, P.ldo, qs + 128 * qb, Tq, lane, oslice);
       const int qrow = qs + 128 * qb + (lane & 31);
       if (half == 0 && qrow < Tq) P.LSE[(size_t)bh * Tq + qrow] = m[qb] * LN2 + __logf(lt);
@@ -331,7 +331,7 @@ __device__ __forceinline__ void dq2_wave(const AttnArgs2& a, const mmf_attn_prob
 #pragma unroll
       for (int e = 0; e < 4; ++e) delta += bf16lo(x[e]) * bf16lo(y[e]) + bf16hi(x[e]) * bf16hi(y[e]);
     }
-    delta += __shfl_xor(delta, 32, 64);
+    delta = half_sum(delta);
     if (half == 0 && qrow < Tq) P.delta[(size_t)bh * Tq + qrow] = delta;
     lse2 = (qrow < Tq ? P.LSE[(size_t)bh * Tq + qrow] : 0.f) * LOG2E;
   }

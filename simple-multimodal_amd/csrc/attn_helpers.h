@@ -13,6 +13,18 @@ constexpr float NEG_BIG = -1.0e30f;
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// Combine a value with its partner in the other half-wave (lane i <-> lane i + 32) without the LDS round trip of
+// ds_bpermute: v_permlane32_swap exchanges lanes 32-63 of its first operand with lanes 0-31 of its second, so with
+// both operands = x the two results hold {x.lo, x.lo} and {x.hi, x.hi} (guide T12 / T21).
+__device__ __forceinline__ float half_max(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float half_sum(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 // ---- LDS tile helpers: image [rows][DH + 8] bf16 ------------------------------------------------
 // Stage a [ROWS][DH] tile of a (T, ld) matrix whose (b, h) origin is `base`; rows >= T read as zero.
 template <int DH, int ROWS>
