@@ -218,11 +218,17 @@ import os as _os
 DEFER_WGRAD = _os.environ.get("MMF_DEFER_WGRAD", "1") != "0"
 _SKINNY = _os.environ.get("MMF_SKINNY", "1") != "0"          # skinny-M kernels for problems with <= 64 rows
 _pending_wgrad: List[tuple] = []
+# Side-stream wgrad (MMF_WGRAD_SIDE=1, experimental A/B): instead of one flush at the end of backward, the queued
+# wgrad problems are issued on a second stream whenever MMF_WGRAD_CHUNK output tiles have accumulated, so the long
+# wgrad GEMMs fill the CUs the dgrad / attention / LayerNorm chain leaves idle (launch tails, latency-bound kernels).
+_WGRAD_SIDE = _os.environ.get("MMF_WGRAD_SIDE", "0") == "1"
+_WGRAD_CHUNK = int(_os.environ.get("MMF_WGRAD_CHUNK", "800"))
+_wgrad_stream: Optional[torch.cuda.Stream] = None
+_callback_queued = False
+_pending_tiles = 0
 
 
-def _flush_wgrad() -> None:
-    global _pending_wgrad
-    pend, _pending_wgrad = _pending_wgrad, []
+def _issue_wgrad(pend: List[tuple]) -> None:
     # (has bias, overwrite) -> problems; overwrite = first wgrad of a lazily-zeroed step (arena.zero_grad(lazy=True))
     groups: dict = {}
     for q in pend:
@@ -233,10 +239,38 @@ def _flush_wgrad() -> None:
         gemm_group(GEMM_TN, group, (0 if overwrite else EPI_ACCUM) | (EPI_COLSUM_A if has_bias else 0))
 
 
+def _issue_wgrad_side(pend: List[tuple]) -> None:
+    global _wgrad_stream
+    if _wgrad_stream is None:
+        _wgrad_stream = torch.cuda.Stream()
+    cur = torch.cuda.current_stream()
+    _wgrad_stream.wait_stream(cur)                       # the queued dy / x are complete on the main stream
+    with torch.cuda.stream(_wgrad_stream):
+        _issue_wgrad(pend)
+    for q in pend:                                       # keep the operands' memory until the side kernels ran
+        q[0].record_stream(_wgrad_stream)
+        q[1].record_stream(_wgrad_stream)
+
+
+def _flush_wgrad() -> None:
+    global _pending_wgrad, _callback_queued, _pending_tiles
+    pend, _pending_wgrad = _pending_wgrad, []
+    _callback_queued, _pending_tiles = False, 0
+    if _WGRAD_SIDE:
+        if pend:
+            _issue_wgrad_side(pend)
+        if _wgrad_stream is not None:
+            torch.cuda.current_stream().wait_stream(_wgrad_stream)      # gradients complete when backward returns
+        return
+    if pend:
+        _issue_wgrad(pend)
+
+
 def queue_wgrad(dy: torch.Tensor, x: torch.Tensor, wgrad: torch.Tensor, bgrad: Optional[torch.Tensor]) -> None:
     """wgrad (f32, [N_out, K_in]) += dy^T x ;  bgrad (f32 [N_out]) += column sums of dy.
     If the gradient lives in an arena that was zeroed lazily this step and nothing has written it yet, the
     GEMM overwrites instead (``ParamArena.take_first_touch``)."""
+    global _callback_queued, _pending_tiles, _pending_wgrad
     overwrite = False
     from .arena import arena_of
     ar = arena_of(wgrad)
@@ -246,9 +280,16 @@ def queue_wgrad(dy: torch.Tensor, x: torch.Tensor, wgrad: torch.Tensor, bgrad: O
         gemm_group(GEMM_TN, [(dy, x, wgrad, bgrad, None)],
                    (0 if overwrite else EPI_ACCUM) | (EPI_COLSUM_A if bgrad is not None else 0))
         return
-    if not _pending_wgrad:
+    if not _callback_queued:
         torch.autograd.Variable._execution_engine.queue_callback(_flush_wgrad)
+        _callback_queued = True
     _pending_wgrad.append((dy, x, wgrad, bgrad, None, overwrite))
+    if _WGRAD_SIDE:
+        _pending_tiles += ((wgrad.shape[0] + 255) // 256) * ((wgrad.shape[1] + 127) // 128)
+        if _pending_tiles >= _WGRAD_CHUNK:
+            pend, _pending_wgrad = _pending_wgrad, []
+            _pending_tiles = 0
+            _issue_wgrad_side(pend)
 
 
 # --------------------------------------------------------------------------------------------

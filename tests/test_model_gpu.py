@@ -1,0 +1,124 @@
+"""GPU parity of the whole model glue (BASELINE configs[4], MELD-shaped):
+``MultimodalEmotionModel`` in feature mode (backbone features in, because the HF backbones cannot be fetched
+offline) against the CPU oracle's composition of the same arithmetic — encoder projection tails, hier-ref
+hierarchical fusion at d = 512 / 8 heads (head_dim 64) / G = 512, classifier and auxiliary heads.
+
+The reference model cannot be instantiated in the build container (its constructor downloads the backbones by
+name), so this level is oracle-vs-HIP: the oracle's pieces are pinned one by one against the
+reference's own classes by the golden fixtures (tests/test_oracle_golden.py), the composition follows
+models/multimodal_model.py:104-181.  The video BiLSTM runs on torch.nn.LSTM on both sides with the same weights.
+Tolerance: outputs 1e-2 * max(1, |ref|max) (north_star bf16 tolerance); gradients by relative L2."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from helpers import l2_rel  # noqa: E402
+from oracle import ref_cpu  # noqa: E402
+
+OUT_ATOL = 1e-2
+
+
+def _build(fusion_type="hierarchical"):
+    import config as cfgmod
+    from models.multimodal_model import MultimodalEmotionModel
+    cfg = cfgmod.ModelConfig()
+    cfg.feature_inputs = True
+    cfg.fusion_type = fusion_type
+    cfg.fusion_hidden_size, cfg.fusion_num_heads = 512, 8            # MELD-shaped: encoder dim 768 -> d = 512
+    cfg.graph_hidden_size, cfg.graph_num_layers = 512, 3
+    cfg.fusion_dropout = cfg.graph_dropout = 0.0
+    torch.manual_seed(5)
+    return cfg, MultimodalEmotionModel(cfg)
+
+
+def _inputs(B=16):
+    g = torch.Generator().manual_seed(1234)
+    text = torch.randn(B, 9, 768, generator=g)
+    audio = torch.randn(B, 21, 768, generator=g)
+    video = torch.randn(B, 6, 768, generator=g)
+    mask = torch.ones(B, 9, dtype=torch.long)
+    return text, mask, audio, video
+
+
+def _oracle(cfg, model, text, mask, audio, video, fusion_type):
+    P = {k: v.detach().float().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    tf = ref_cpu.text_projection_tail(P, "text_encoder.", text, mask, cls_pool=True)
+    af, _ = ref_cpu.seq_projection_tail(P, "audio_encoder.", audio, "temporal_attention")
+    lstm = torch.nn.LSTM(768, 384, num_layers=2, batch_first=True, bidirectional=True)
+    lstm.load_state_dict({k[len("video_encoder.temporal_lstm."):]: v.detach().cpu() for k, v in model.state_dict().items()
+                          if k.startswith("video_encoder.temporal_lstm.")})
+    with torch.no_grad():
+        lstm_out, _ = lstm(video)
+    vf, _ = ref_cpu.seq_projection_tail(P, "video_encoder.", lstm_out, "facial_attention")
+    if fusion_type == "hierarchical":
+        fo = ref_cpu.hierarchical_fusion(P, "fusion_layer.", tf, af, vf, num_heads=cfg.fusion_num_heads,
+                                         graph_num_layers=cfg.graph_num_layers, temperature=cfg.contrastive_temperature,
+                                         compute_contrastive_loss=True)
+        fused = fo["fused_features"]
+        out = ref_cpu.model_heads(P, fused)
+        out.update({k: v for k, v in fo.items() if k != "fused_features"})
+    else:
+        fo = ref_cpu.late_fusion(P, "fusion_layer.", tf, af, vf)
+        head_in = (tf + af + vf) / 3
+        out = {"emotion_logits": fo["fused_logits"], "emotion_probs": ref_cpu.softmax_lastdim(fo["fused_logits"]),
+               "valence": ref_cpu.linear(head_in, P["valence_regressor.weight"], P["valence_regressor.bias"]),
+               "arousal": ref_cpu.linear(head_in, P["arousal_regressor.weight"], P["arousal_regressor.bias"]),
+               "uncertainty": ref_cpu.softmax_lastdim(ref_cpu.linear(head_in, P["uncertainty_head.weight"],
+                                                                      P["uncertainty_head.bias"])),
+               "fusion_weights": fo["fusion_weights"]}
+    out.update({"text_features": tf, "audio_features": af, "video_features": vf})
+    return P, out
+
+
+def _loss(out, labels):
+    loss = torch.nn.functional.cross_entropy(out["emotion_logits"].float(), labels, label_smoothing=0.1)
+    loss = loss + out["valence"].float().sum() * 0.01 + out["arousal"].float().sum() * 0.01
+    if isinstance(out.get("contrastive_losses"), dict) and out["contrastive_losses"]:
+        loss = loss + 0.1 * sum(out["contrastive_losses"].values())
+    return loss
+
+
+@pytest.mark.parametrize("fusion_type", ["hierarchical", "late"])
+def test_meld_shaped_model_matches_oracle(fusion_type):
+    cfg, model = _build(fusion_type)
+    text, mask, audio, video = _inputs()
+    labels = torch.randint(0, 7, (text.shape[0],), generator=torch.Generator().manual_seed(7))
+    P, ref = _oracle(cfg, model, text, mask, audio, video, fusion_type)
+    _loss(ref, labels).backward()
+
+    # training mode with every dropout probability at zero (MIOpen's LSTM backward needs training mode; the
+    # ModalityDropout masks are all-ones at rate 0), so the arithmetic is the oracle's
+    model = model.cuda().train()
+    model.modality_dropout.dropout_rate = 0.0
+    kw = dict(compute_contrastive_loss=True) if fusion_type == "hierarchical" else {}
+    out = model({"input_ids": text.cuda(), "attention_mask": mask.cuda()}, audio.cuda(), video.cuda(), **kw)
+    _loss(out, labels.cuda()).backward()
+    torch.cuda.synchronize()
+
+    keys = ["emotion_logits", "emotion_probs", "valence", "arousal", "uncertainty", "text_features", "audio_features",
+            "video_features"]
+    if fusion_type == "hierarchical":
+        keys += ["early_features", "mult_features", "graph_features", "contrastive_features", "adaptive_features",
+                 "adaptive_weights"]
+    for k in keys:
+        got, want = out[k].detach().float().cpu(), ref[k].detach()
+        assert got.shape == want.shape, k
+        err = float((got - want).abs().max())
+        assert err <= OUT_ATOL * max(1.0, float(want.abs().max())), f"{fusion_type}: {k} abs err {err:.3e}"
+    if fusion_type == "hierarchical":
+        for k, want in ref["contrastive_losses"].items():
+            got = float(out["contrastive_losses"][k].detach())
+            assert abs(got - float(want.detach())) <= 2e-2 * max(1.0, abs(float(want.detach()))), k
+    # gradients of the head and projection parameters (the glue this test is about); the fusion layers'
+    # gradients are covered by tests/test_parity_gpu.py
+    names = ["text_encoder.projection.weight", "audio_encoder.projection.weight", "video_encoder.projection.weight",
+             "valence_regressor.weight", "arousal_regressor.weight"]
+    names += ["classifier.classifier.3.weight", "classifier.classifier.0.weight"] if fusion_type == "hierarchical" else \
+        ["fusion_layer.text_classifier.weight", "fusion_layer.audio_classifier.bias"]
+    params = dict(model.named_parameters())
+    for n in names:
+        want = P[n].grad
+        assert want is not None, n
+        got = params[n].grad.detach().float().cpu()
+        assert l2_rel(got, want) <= 0.2, f"{fusion_type}: grad {n} rel L2 {l2_rel(got, want):.3e}"
