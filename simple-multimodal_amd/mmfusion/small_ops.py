@@ -45,6 +45,27 @@ def cat3(t: torch.Tensor, a: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
     return torch.cat([t.float(), a.float(), v.float()], dim=-1)
 
 
+class _Split3(torch.autograd.Function):
+    """The three column thirds of a (B, 3d) tensor as row-strided views.  Plain slicing would do, but its backward
+    is three zero-fills plus three copies; this one is a single ``torch.cat``."""
+
+    @staticmethod
+    def forward(ctx, c):
+        d = c.shape[1] // 3
+        ctx.meta = (c.shape[0], d, c.dtype, c.device)
+        return c[:, :d], c[:, d:2 * d], c[:, 2 * d:]
+
+    @staticmethod
+    def backward(ctx, g0, g1, g2):
+        B, d, dtype, dev = ctx.meta
+        gs = [g if g is not None else torch.zeros((B, d), dtype=dtype, device=dev) for g in (g0, g1, g2)]
+        return torch.cat([g.to(dtype) for g in gs], dim=1)
+
+
+def split3(c: torch.Tensor):
+    return _Split3.apply(c)
+
+
 class _Stack3Embed(torch.autograd.Function):
     """x[b][m][:] = cat3[b][m*d:(m+1)*d] + emb[m][:]  ->  bf16 (B*3, d) rows (GraphFusion :255-264; emb None =
     plain stacking)."""

@@ -366,7 +366,7 @@ class ContrastiveFusion(_FusionBase):
         p = _p(self, self.config.fusion_dropout)
         d = text_features.shape[-1]
         _, cat = _cat3(text_features, audio_features, video_features)                  # bf16 (B, 3d)
-        xs = [cat[:, i * d:(i + 1) * d] for i in range(3)]
+        xs = list(sops.split3(cat))
         projs = [self.text_projector, self.audio_projector, self.video_projector]
         h = ops.linear_group([(x, _lin(p[0], relu=True), None) for x, p in zip(xs, projs)])
         z = ops.linear_group([(hh, _lin(p[2]), None) for hh, p in zip(h, projs)], out_f32=True)
@@ -415,7 +415,7 @@ class AdaptiveFusion(_FusionBase):
         mp = self.attention
         H, dh = mp.num_heads, mp.head_dim
         _, cat = _cat3(text_features, audio_features, video_features)                  # bf16 (B, 3d)
-        xs = [cat[:, i * d:(i + 1) * d] for i in range(3)]
+        xs = list(sops.split3(cat))
         tr = ops.linear_group([(x, _lin(l), None) for x, l in
                                zip(xs, (self.text_transform, self.audio_transform, self.video_transform))])
         stacked = torch.stack(tr, dim=1).reshape(B * 3, d)                             # (B,3,d) :427-429
