@@ -14,34 +14,55 @@ inline int ew_grid(int64_t nvec) {
   return (int)g;
 }
 
+// f32 -> bf16.  A lane converts 4 consecutive floats per access (16-B load, 8-B store): every load
+// wave-instruction covers 1 KiB contiguous (the first version gave each lane 8 consecutive floats = two 16-B loads
+// 32 B apart, i.e. two half-used passes over the same cache lines: 2.5 TB/s on the 206 MB weight arena), and four
+// independent accesses are in flight per lane.
 __global__ __launch_bounds__(EW_THREADS)
 void cast_f32_bf16_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, int64_t n) {
-  const int64_t nvec = n >> 3;
+  const int64_t nvec = n >> 2;
   const int64_t stride = (int64_t)gridDim.x * EW_THREADS;
-  for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < nvec; i += stride) {
-    const f32x4_t a = *reinterpret_cast<const f32x4_t*>(src + i * 8);
-    const f32x4_t b = *reinterpret_cast<const f32x4_t*>(src + i * 8 + 4);
-    u32x4_t o = {pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(b[0], b[1]),
-                 pack_bf16x2(b[2], b[3])};
-    *reinterpret_cast<u32x4_t*>(dst + i * 8) = o;
+  int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x;
+  for (; i + 3 * stride < nvec; i += 4 * stride) {
+    f32x4_t a[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) a[u] = *reinterpret_cast<const f32x4_t*>(src + (i + u * stride) * 4);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      *reinterpret_cast<u32x2_t*>(dst + (i + u * stride) * 4) = u32x2_t{pack_bf16x2(a[u][0], a[u][1]), pack_bf16x2(a[u][2], a[u][3])};
   }
-  if (blockIdx.x == 0) {                              // tail (n % 8 elements)
-    const int64_t t = (nvec << 3) + threadIdx.x;
+  for (; i < nvec; i += stride) {
+    const f32x4_t a = *reinterpret_cast<const f32x4_t*>(src + i * 4);
+    *reinterpret_cast<u32x2_t*>(dst + i * 4) = u32x2_t{pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3])};
+  }
+  if (blockIdx.x == 0) {                              // tail (n % 4 elements)
+    const int64_t t = (nvec << 2) + threadIdx.x;
     if (t < n) dst[t] = f32_to_bf16_bits(src[t]);
   }
 }
 
+// bf16 -> f32 (* scale): a lane widens 4 consecutive values per access (8-B load, 16-B store), so every store
+// wave-instruction covers 1 KiB contiguous; four independent accesses in flight per lane.
 __global__ __launch_bounds__(EW_THREADS)
 void cast_bf16_f32_kernel(const unsigned short* __restrict__ src, float* __restrict__ dst, int64_t n, const float scale) {
-  const int64_t nvec = n >> 3;
+  const int64_t nvec = n >> 2;
   const int64_t stride = (int64_t)gridDim.x * EW_THREADS;
-  for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < nvec; i += stride) {
-    const u32x4_t w = *reinterpret_cast<const u32x4_t*>(src + i * 8);
-    *reinterpret_cast<f32x4_t*>(dst + i * 8) = f32x4_t{bf16lo(w[0]), bf16hi(w[0]), bf16lo(w[1]), bf16hi(w[1])} * scale;
-    *reinterpret_cast<f32x4_t*>(dst + i * 8 + 4) = f32x4_t{bf16lo(w[2]), bf16hi(w[2]), bf16lo(w[3]), bf16hi(w[3])} * scale;
+  int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x;
+  for (; i + 3 * stride < nvec; i += 4 * stride) {
+    u32x2_t w[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) w[u] = *reinterpret_cast<const u32x2_t*>(src + (i + u * stride) * 4);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      *reinterpret_cast<f32x4_t*>(dst + (i + u * stride) * 4) =
+          f32x4_t{bf16lo(w[u][0]), bf16hi(w[u][0]), bf16lo(w[u][1]), bf16hi(w[u][1])} * scale;
+  }
+  for (; i < nvec; i += stride) {
+    const u32x2_t w = *reinterpret_cast<const u32x2_t*>(src + i * 4);
+    *reinterpret_cast<f32x4_t*>(dst + i * 4) = f32x4_t{bf16lo(w[0]), bf16hi(w[0]), bf16lo(w[1]), bf16hi(w[1])} * scale;
   }
   if (blockIdx.x == 0) {
-    const int64_t t = (nvec << 3) + threadIdx.x;
+    const int64_t t = (nvec << 2) + threadIdx.x;
     if (t < n) dst[t] = bf16_bits_to_f32(src[t]) * scale;
   }
 }
@@ -230,7 +251,7 @@ void colsum_kernel(const ColsumArgs a) {
 extern "C" int mmf_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream) {
   if (n <= 0) return MMF_OK;
   EW_PTR_CHECK("mmf_cast_f32_to_bf16", src && dst && mmf_aligned16(src) && mmf_aligned16(dst));
-  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(ew_grid(n >> 3)), dim3(EW_THREADS), 0,
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(ew_grid(n >> 4)), dim3(EW_THREADS), 0,
                      static_cast<hipStream_t>(stream), src, static_cast<unsigned short*>(dst), n);
   MMF_CHECK_LAUNCH("mmf_cast_f32_to_bf16");
   return MMF_OK;
@@ -239,7 +260,7 @@ extern "C" int mmf_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void
 extern "C" int mmf_cast_bf16_to_f32_scaled(const void* src, float* dst, int64_t n, float scale, void* stream) {
   if (n <= 0) return MMF_OK;
   EW_PTR_CHECK("mmf_cast_bf16_to_f32", src && dst && mmf_aligned16(src) && mmf_aligned16(dst));
-  hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(ew_grid(n >> 3)), dim3(EW_THREADS), 0,
+  hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(ew_grid(n >> 4)), dim3(EW_THREADS), 0,
                      static_cast<hipStream_t>(stream), static_cast<const unsigned short*>(src), dst, n, scale);
   MMF_CHECK_LAUNCH("mmf_cast_bf16_to_f32");
   return MMF_OK;
