@@ -3,13 +3,20 @@
 // f32 statistics by wave butterfly reduction, no LDS in the forward.
 // Algorithmic bytes per row: forward 2 x 2d (x in, y out) + 8; backward 3 x 2d (x, dy in; dx out).
 #include "mmf_internal.h"
+#include <stdlib.h>
 
 namespace {
 
 constexpr int ROWS_PER_BLOCK = 4;      // 4 waves, one row each
 constexpr int MAX_CH = 4;              // 4 chunks x 64 lanes x 8 elements = 2048 columns
 
-constexpr int BWD_BLOCK_BUDGET = 512;   // ~2 workgroups per CU for the whole grouped backward launch
+constexpr int BWD_BLOCK_BUDGET = 2048;  // upper bound of workgroups of a grouped backward launch (workspace rows)
+// workgroups actually used (MMF_LN_BWD_BLOCKS, default below): enough rows in flight per CU to cover the HBM latency
+static int bwd_blocks() {
+  static const int v = [] { const char* e = getenv("MMF_LN_BWD_BLOCKS"); int b = e ? atoi(e) : 2048;
+                            return b < 64 ? 64 : (b > BWD_BLOCK_BUDGET ? BWD_BLOCK_BUDGET : b); }();
+  return v;
+}
 
 struct LnArgs {
   int nprob;
@@ -186,7 +193,7 @@ void ln_bwd_kernel(const LnArgs a) {
 // second phase: dgamma[j] += sum over the problem's workgroups of their partials.  thread = column,
 // blockIdx.z = one of FIN_SLICES slices of the workgroup range; each slice ends in one f32 atomic per
 // column (FIN_SLICES adders per address).
-constexpr int FIN_SLICES = 8;
+constexpr int FIN_SLICES = 32;
 __global__ __launch_bounds__(256)
 void ln_bwd_finalize_kernel(const LnArgs a) {
   const int pi = blockIdx.y;
@@ -267,7 +274,7 @@ extern "C" int mmf_layernorm_bwd_grouped(const mmf_ln_problem* problems, int num
   // Workgroups are shared out over the problems in proportion to their rows (~2 per CU in total);
   // each leaves one row of column partials in the workspace (same-row float atomics would run ~14x
   // below the streaming rate: MI355X_MICROARCH.md, Global float atomics), summed by the finalize pass.
-  const int budget = BWD_BLOCK_BUDGET;
+  const int budget = bwd_blocks();
   for (int i = 0; i < num_problems; ++i) {
     const int rows = problems[i].rows;
     int nb = (int)(((long long)rows * budget + total_rows - 1) / total_rows);
