@@ -481,9 +481,11 @@ int mmf_attn_fwd2_launch(const mmf_attn_problem* problems, int n, int head_dim, 
                          const uint64_t* rng_state, uint32_t site, hipStream_t s);
 int mmf_attn_bwd2_launch(const mmf_attn_problem* problems, int n, int head_dim, float scale, float drop_p,
                          const uint64_t* rng_state, uint32_t site, hipStream_t s);
-static int g_attn_impl = 0;       // 0 automatic (second generation), 1 first generation, 2 second generation
+int mmf_attn_fwd3_launch(const mmf_attn_problem* problems, int n, int head_dim, float scale, float drop_p,
+                         const uint64_t* rng_state, uint32_t site, hipStream_t s);
+static int g_attn_impl = 0;       // 0 automatic, 1 first generation, 2 second generation, 3 third-generation forward
 extern "C" int mmf_attn_select_impl(int impl) {
-  if (impl < 0 || impl > 2) MMF_FAIL(MMF_E_UNSUPPORTED, "mmf_attn_select_impl: impl=%d (0 auto, 1, 2)", impl);
+  if (impl < 0 || impl > 3) MMF_FAIL(MMF_E_UNSUPPORTED, "mmf_attn_select_impl: impl=%d (0 auto, 1, 2, 3)", impl);
   g_attn_impl = impl;
   return MMF_OK;
 }
@@ -494,6 +496,9 @@ extern "C" int mmf_attn_fwd_grouped_ex(const mmf_attn_problem* problems, int num
   if (int rc = validate("mmf_attn_fwd_grouped", problems, num_problems, head_dim, false)) return rc;
   if (!(dropout_p >= 0.f) || dropout_p >= 1.f || (dropout_p > 0.f && !rng_state))
     MMF_FAIL(MMF_E_SHAPE, "mmf_attn_fwd_grouped_ex: dropout needs 0 <= p < 1 and an rng_state");
+  if (g_attn_impl == 3)
+    return mmf_attn_fwd3_launch(problems, num_problems, head_dim, scale, dropout_p, rng_state, site,
+                                static_cast<hipStream_t>(stream));
   if (g_attn_impl != 1 && !getenv("MMF_ATTN_DEBUG"))
     return mmf_attn_fwd2_launch(problems, num_problems, head_dim, scale, dropout_p, rng_state, site,
                                 static_cast<hipStream_t>(stream));

@@ -14,7 +14,7 @@ import torch
 from mmfusion import lib
 
 B, H, dh, d = 16, 8, 96, 768
-T = dict(t=512, a=400, v=30)
+T = dict(t=int(os.environ.get("MMF_ATTN_TT", 512)), a=int(os.environ.get("MMF_ATTN_TA", 400)), v=30)
 INNER, REPS = 10, 10
 
 
@@ -73,7 +73,7 @@ def run(pairs, bwd):
 cross = [("t", "a"), ("t", "v"), ("a", "t"), ("a", "v"), ("v", "t"), ("v", "a")]
 selfp = [("t", "t"), ("a", "a"), ("v", "v")]
 what = sys.argv[1] if len(sys.argv) > 1 else "fwd"
-impls = [int(x) for x in os.environ.get("MMF_ATTN_IMPLS", "1,2").split(",")]
+impls = [int(x) for x in os.environ.get("MMF_ATTN_IMPLS", "1,2,3").split(",")]
 cases = [("cross x6", cross), ("self x3", selfp), ("t<-a only", [("t", "a")]), ("a<-t only", [("a", "t")]),
          ("t<-t only", [("t", "t")]), ("v<-t only", [("v", "t")]), ("t<-v only", [("t", "v")])]
 if os.environ.get("MMF_ATTN_CASES"):
