@@ -486,3 +486,33 @@ def test_stack3_embed_and_rowmask():
     ym = sops.rowmask(xm, m)
     ym.backward(torch.ones_like(ym))
     assert torch.equal(ym, xm.detach() * m[:, None]) and torch.equal(xm.grad, m[:, None].expand(B, d))
+
+
+@pytest.mark.parametrize("impl", [1, 2, 3])
+@pytest.mark.parametrize("Tq,Tk", [(512, 400), (400, 512), (30, 512), (512, 30), (300, 97), (257, 65)])
+def test_attention_generations_at_mult_shapes(impl, Tq, Tk):
+    """Every attention generation (mmf_attn_select_impl) on the MulT sequence shapes: several 256-row query chunks
+    with balanced sizes (400 -> 224 + 176), ragged last tiles whose second 32-key block is pure padding (400 = 6
+    tiles + 16 keys), one-block problems (30), and the rescale of the running maximum in a late tile."""
+    from mmfusion import lib
+    B, H, dh = 2, 8, 96
+    d = H * dh
+    q, kv, do = rnd(B, Tq, d, seed=31), rnd(B, Tk, 2 * d, seed=32), rnd(B, Tq, d, seed=33)
+    kv[0, Tk - 3, :dh] = q[0, min(Tq - 1, 7), :dh] * 3.0        # a late key far above the rest for one (b, h, query)
+    q16 = bf(q).reshape(B * Tq, d).requires_grad_(True)
+    kv16 = bf(kv).reshape(B * Tk, 2 * d).requires_grad_(True)
+    lib.check(lib.load().mmf_attn_select_impl(impl))
+    try:
+        o = ops.attention_group([ops.AttnSpec(B, Tq, Tk, q=(0, 0), k=(1, 0), v=(1, d))], H, dh, [q16, kv16])[0]
+        o.backward(bf(do).reshape(B * Tq, d))
+        torch.cuda.synchronize()
+    finally:
+        lib.check(lib.load().mmf_attn_select_impl(0))
+    qr = q16.detach().float().cpu().view(B, Tq, d).requires_grad_(True)
+    kvr = kv16.detach().float().cpu().view(B, Tk, 2 * d).requires_grad_(True)
+    orf = attn_ref(qr, kvr[..., :d], kvr[..., d:], H)
+    orf.backward(bf(do).float().cpu())
+    assert rel(o.view(B, Tq, d), orf.detach()) < 2 ** -7
+    assert rel(q16.grad.view(B, Tq, d), qr.grad) < 2e-2
+    assert rel(kv16.grad.view(B, Tk, 2 * d)[..., :d], kvr.grad[..., :d]) < 2e-2
+    assert rel(kv16.grad.view(B, Tk, 2 * d)[..., d:], kvr.grad[..., d:]) < 2e-2
