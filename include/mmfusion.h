@@ -234,6 +234,11 @@ int mmf_colsum_grouped(const mmf_colsum_problem* problems, int num_problems, voi
  * The same call with the same (*rng_state, site) on dy gives the backward.  In place allowed. */
 int mmf_dropout(const void* x, void* y, int64_t n, int is_f32, float p, const uint64_t* rng_state,
                 uint32_t site, void* stream);
+/* base[starts[r] .. ends[r]) = 0 for up to MMF_ZERO_MAX_RANGES float ranges in ONE launch: the holes of the lazily
+ * zeroed gradient arena (biases, LayerNorm vectors, gradients torch produces) between the matrices the wgrad GEMMs
+ * overwrite.  base 16-byte aligned; starts / ends are HOST arrays of element offsets. */
+#define MMF_ZERO_MAX_RANGES 48
+int mmf_zero_ranges_f32(float* base, const int64_t* starts, const int64_t* ends, int n, void* stream);
 /* relu backward on bf16: dx = dy * (y > 0) */
 int mmf_relu_bwd_bf16(const void* dy, const void* y, void* dx, int64_t n, void* stream);
 

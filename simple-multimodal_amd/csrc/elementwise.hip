@@ -244,6 +244,27 @@ void colsum_kernel(const ColsumArgs a) {
   }
 }
 
+// zero up to MMF_ZERO_MAX_RANGES [start, end) float ranges of one buffer in ONE launch (the lazily-zeroed gradient
+// arena's unmanaged holes: biases, LayerNorm vectors, torch-produced gradients)
+struct ZeroArgs { float* base; int n; long long start[MMF_ZERO_MAX_RANGES]; long long end[MMF_ZERO_MAX_RANGES]; int blk_start[MMF_ZERO_MAX_RANGES + 1]; };
+__global__ __launch_bounds__(EW_THREADS)
+void zero_ranges_kernel(const ZeroArgs a) {
+  int r = 0;
+  while (r + 1 < a.n && (int)blockIdx.x >= a.blk_start[r + 1]) ++r;
+  const int nb = a.blk_start[r + 1] - a.blk_start[r];
+  const long long s0 = a.start[r], e0 = a.end[r];
+  // 16-byte stores on the aligned middle, scalar stores on the edges
+  const long long s4 = (s0 + 3) & ~3LL, e4 = e0 & ~3LL;
+  float* p = a.base;
+  const long long stride = (long long)nb * EW_THREADS * 4;
+  for (long long i = s4 + ((long long)(blockIdx.x - a.blk_start[r]) * EW_THREADS + threadIdx.x) * 4; i + 4 <= e4; i += stride)
+    *reinterpret_cast<f32x4_t*>(p + i) = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  if ((int)blockIdx.x == a.blk_start[r]) {
+    for (long long i = s0 + threadIdx.x; i < (s4 < e0 ? s4 : e0); i += EW_THREADS) p[i] = 0.f;
+    for (long long i = (e4 > s4 ? e4 : s4) + threadIdx.x; i < e0; i += EW_THREADS) p[i] = 0.f;
+  }
+}
+
 }  // namespace
 
 #define EW_PTR_CHECK(name, cond) do { if (!(cond)) MMF_FAIL(MMF_E_ALIGN, name ": null or not 16-byte aligned pointer"); } while (0)
@@ -351,4 +372,26 @@ extern "C" int mmf_colsum_bf16(const void* x, float* out, int M, int N, int ldx,
   mmf_colsum_problem p;
   p.x = x; p.out = out; p.M = M; p.N = N; p.ldx = ldx;
   return mmf_colsum_grouped(&p, 1, stream);
+}
+
+extern "C" int mmf_zero_ranges_f32(float* base, const int64_t* starts, const int64_t* ends, int n, void* stream) {
+  if (n <= 0) return MMF_OK;
+  if (!base || !starts || !ends || n > MMF_ZERO_MAX_RANGES || (reinterpret_cast<uintptr_t>(base) & 15))
+    MMF_FAIL(MMF_E_SHAPE, "mmf_zero_ranges_f32: null / misaligned base or n=%d outside [1,%d]", n, MMF_ZERO_MAX_RANGES);
+  ZeroArgs a;
+  a.base = base; a.n = n;
+  int total = 0;
+  for (int r = 0; r < n; ++r) {
+    if (ends[r] < starts[r] || starts[r] < 0) MMF_FAIL(MMF_E_SHAPE, "mmf_zero_ranges_f32: bad range %d", r);
+    a.start[r] = starts[r]; a.end[r] = ends[r];
+    a.blk_start[r] = total;
+    long long nb = ((ends[r] - starts[r]) / 4 + EW_THREADS - 1) / EW_THREADS;
+    if (nb < 1) nb = 1;
+    if (nb > 512) nb = 512;
+    total += (int)nb;
+  }
+  a.blk_start[n] = total;
+  hipLaunchKernelGGL(zero_ranges_kernel, dim3(total), dim3(EW_THREADS), 0, static_cast<hipStream_t>(stream), a);
+  MMF_CHECK_LAUNCH("mmf_zero_ranges_f32");
+  return MMF_OK;
 }

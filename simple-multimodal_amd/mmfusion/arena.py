@@ -68,9 +68,9 @@ class ParamArena:
         # stable: attention in-projections first, then the other matrices, then the vectors (biases, LayerNorm):
         # the matrices' gradients are produced by the wgrad GEMMs, which can overwrite instead of accumulate
         # (zero_grad(lazy=True)), so what still needs a memset each step is the contiguous tail
-        named.sort(key=lambda np_: 0 if _is_early(np_[0]) else (1 if np_[1].dim() >= 2 else 2))
+        named.sort(key=lambda np_: 2 if np_[1].dim() < 2 else (0 if _is_early(np_[0]) else 1))
         params: List[torch.nn.Parameter] = [p for _, p in named]
-        n_early = sum(1 for n, _ in named if _is_early(n))
+        n_early = sum(1 for n, q in named if _is_early(n) and q.dim() >= 2)
         dev = params[0].device
         if dev.type != "cuda":
             raise RuntimeError("mmfusion: the fusion path runs on the GPU only; move the module to a "
@@ -155,8 +155,15 @@ class ParamArena:
         contiguous ranges.  Saves the 4 B/param memset and the wgrad epilogue's read of the old value."""
         if lazy and LAZY_ZERO and self._managed and self.grads.is_cuda:
             self.join()
-            for s0, e0 in self._unmanaged_ranges():
-                self.grads[s0:e0].zero_()
+            ranges = self._unmanaged_ranges()
+            if 0 < len(ranges) <= lib.ZERO_MAX_RANGES:          # every hole in ONE launch
+                import ctypes as C
+                n = len(ranges)
+                st, en = (C.c_int64 * n)(*[r[0] for r in ranges]), (C.c_int64 * n)(*[r[1] for r in ranges])
+                lib.check(lib.load().mmf_zero_ranges_f32(self.grads.data_ptr(), st, en, n, lib.stream_ptr()))
+            else:
+                for s0, e0 in ranges:
+                    self.grads[s0:e0].zero_()
             self._lazy = set(self._managed)
             return
         self._lazy = None

@@ -29,7 +29,7 @@ SYMBOLS = (
     "mmf_sqnorm_f32", "mmf_adamw_step", "mmf_skinny_linear_fwd", "mmf_skinny_linear_dgrad",
     "mmf_gat3_dense_fwd", "mmf_gat3_dense_bwd", "mmf_infonce_fwd", "mmf_infonce_bwd", "mmf_adaptive_combine_fwd",
     "mmf_adaptive_combine_bwd", "mmf_linear_narrow_fwd", "mmf_linear_narrow_bwd", "mmf_stack3_embed_fwd",
-    "mmf_stack3_embed_bwd", "mmf_rowmask_apply",
+    "mmf_stack3_embed_bwd", "mmf_rowmask_apply", "mmf_zero_ranges_f32",
 )
 
 
@@ -64,6 +64,7 @@ class SkinnyProblem(C.Structure):
 
 
 SKINNY_MAX_M, SKINNY_MAX_PROBLEMS = 64, 24
+ZERO_MAX_RANGES = 48
 
 
 class Gat3Params(C.Structure):
@@ -130,6 +131,7 @@ def load() -> C.CDLL:
     lib.mmf_stack3_embed_fwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp]
     lib.mmf_stack3_embed_bwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp]
     lib.mmf_rowmask_apply.argtypes = [vp, vp, vp, i32, i32, vp]
+    lib.mmf_zero_ranges_f32.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), i32, vp]
     lib.mmf_adamw_step.argtypes = [vp, vp, vp, vp, vp, i64, vp, vp, vp]
     for name in SYMBOLS:
         getattr(lib, name)          # AttributeError here = header and .so disagree
