@@ -220,6 +220,12 @@ int mmf_add3_bf16(const void* a, const void* b, const void* c, void* y, int64_t 
 int mmf_meanpool_fwd(const void* x, void* y, int B, int T, int d, int ldy, void* stream);
 /* dx[b][t][j] = dy[b][j] / T ; dy bf16 with row stride lddy */
 int mmf_meanpool_bwd(const void* dy, void* dx, int B, int T, int d, int lddy, void* stream);
+/* the n (<= MMF_POOL_MAX) modalities of :166-171 in one launch: problem i pools xs[i] (B, Ts[i], d) into columns
+ * [i d, (i+1) d) of y; backward scatters dy's column blocks back (dxs[i] bf16 (B, Ts[i], d)).  xs / dxs / Ts are
+ * HOST arrays. */
+#define MMF_POOL_MAX 4
+int mmf_meanpool_cat_fwd(const void* const* xs, const int* Ts, int n, void* y, int B, int d, int ldy, void* stream);
+int mmf_meanpool_cat_bwd(const void* dy, void* const* dxs, const int* Ts, int n, int B, int d, int lddy, void* stream);
 /* out[n] (+)= sum_m x[m][n]; x bf16 [M][ldx]; out f32, atomically accumulated (bias gradients:
  * the column sums of dy for nn.Linear biases).  The grouped form covers several matrices in one launch. */
 int mmf_colsum_bf16(const void* x, float* out, int M, int N, int ldx, void* stream);

@@ -244,6 +244,59 @@ void colsum_kernel(const ColsumArgs a) {
   }
 }
 
+// grouped mean over T + concatenation: problem i pools x_i (B, T_i, d) into columns [i d, (i+1) d) of y (B, ldy);
+// one launch for the three modalities (reference models/fusion_layers.py:166-171) instead of three 96-workgroup ones
+struct PoolArgs { const unsigned short* x[MMF_POOL_MAX]; unsigned short* g[MMF_POOL_MAX]; int T[MMF_POOL_MAX]; int blk_start[MMF_POOL_MAX + 1]; int n, B, d, ld; };
+__global__ __launch_bounds__(256)
+void meanpool_cat_fwd_kernel(const PoolArgs a, unsigned short* __restrict__ y) {
+  __shared__ float red[16][128 + 4];
+  const int i = blockIdx.z, T = a.T[i], d = a.d;
+  const int b = blockIdx.x, cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const int col = blockIdx.y * 128 + cl * 8;
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (col < d) {
+    const unsigned short* p = a.x[i] + (size_t)b * T * d + col;
+    for (int t = rg; t < T; t += 16) {
+      const u32x4_t w = *reinterpret_cast<const u32x4_t*>(p + (size_t)t * d);
+      s[0] += bf16lo(w[0]); s[1] += bf16hi(w[0]); s[2] += bf16lo(w[1]); s[3] += bf16hi(w[1]);
+      s[4] += bf16lo(w[2]); s[5] += bf16hi(w[2]); s[6] += bf16lo(w[3]); s[7] += bf16hi(w[3]);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[rg][cl * 8 + e] = s[e];
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    const int c = blockIdx.y * 128 + threadIdx.x;
+    if (c < d) {
+      float t = 0.f;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) t += red[g][threadIdx.x];
+      y[(size_t)b * a.ld + i * d + c] = f32_to_bf16_bits(t / (float)T);
+    }
+  }
+}
+// backward: dx_i[b][t][:] = dy[b][i d : (i+1) d] / T_i
+__global__ __launch_bounds__(EW_THREADS)
+void meanpool_cat_bwd_kernel(const PoolArgs a, const unsigned short* __restrict__ dy) {
+  int i = 0;
+  while (i + 1 < a.n && (int)blockIdx.x >= a.blk_start[i + 1]) ++i;
+  const int T = a.T[i], d = a.d, dv = d >> 3;
+  const int64_t nvec = (int64_t)a.B * T * dv;
+  const float inv = 1.f / (float)T;
+  const int nb = a.blk_start[i + 1] - a.blk_start[i];
+  const int64_t stride = (int64_t)nb * EW_THREADS;
+  unsigned short* dx = a.g[i];
+  for (int64_t v = (int64_t)(blockIdx.x - a.blk_start[i]) * EW_THREADS + threadIdx.x; v < nvec; v += stride) {
+    const int c = (int)(v % dv);
+    const int b = (int)(v / ((int64_t)T * dv));
+    const u32x4_t w = *reinterpret_cast<const u32x4_t*>(dy + (size_t)b * a.ld + i * d + c * 8);
+    u32x4_t o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(bf16lo(w[e]) * inv, bf16hi(w[e]) * inv);
+    *reinterpret_cast<u32x4_t*>(dx + v * 8) = o;
+  }
+}
+
 // zero up to MMF_ZERO_MAX_RANGES [start, end) float ranges of one buffer in ONE launch (the lazily-zeroed gradient
 // arena's unmanaged holes: biases, LayerNorm vectors, torch-produced gradients)
 struct ZeroArgs { float* base; int n; long long start[MMF_ZERO_MAX_RANGES]; long long end[MMF_ZERO_MAX_RANGES]; int blk_start[MMF_ZERO_MAX_RANGES + 1]; };
@@ -393,5 +446,39 @@ extern "C" int mmf_zero_ranges_f32(float* base, const int64_t* starts, const int
   a.blk_start[n] = total;
   hipLaunchKernelGGL(zero_ranges_kernel, dim3(total), dim3(EW_THREADS), 0, static_cast<hipStream_t>(stream), a);
   MMF_CHECK_LAUNCH("mmf_zero_ranges_f32");
+  return MMF_OK;
+}
+
+extern "C" int mmf_meanpool_cat_fwd(const void* const* xs, const int* Ts, int n, void* y, int B, int d, int ldy, void* stream) {
+  if (!xs || !Ts || !y || n <= 0 || n > MMF_POOL_MAX || B <= 0 || d <= 0 || (d & 7) || (ldy & 7) || ldy < n * d)
+    MMF_FAIL(MMF_E_SHAPE, "mmf_meanpool_cat_fwd: n=%d B=%d d=%d ldy=%d", n, B, d, ldy);
+  PoolArgs a = {};
+  a.n = n; a.B = B; a.d = d; a.ld = ldy;
+  for (int i = 0; i < n; ++i) {
+    if (!xs[i] || Ts[i] <= 0 || !mmf_aligned16(xs[i])) MMF_FAIL(MMF_E_SHAPE, "mmf_meanpool_cat_fwd[%d]: bad operand", i);
+    a.x[i] = static_cast<const unsigned short*>(xs[i]); a.T[i] = Ts[i];
+  }
+  hipLaunchKernelGGL(meanpool_cat_fwd_kernel, dim3(B, (d + 127) / 128, n), dim3(256), 0, static_cast<hipStream_t>(stream), a,
+                     static_cast<unsigned short*>(y));
+  MMF_CHECK_LAUNCH("mmf_meanpool_cat_fwd");
+  return MMF_OK;
+}
+
+extern "C" int mmf_meanpool_cat_bwd(const void* dy, void* const* dxs, const int* Ts, int n, int B, int d, int lddy, void* stream) {
+  if (!dy || !dxs || !Ts || n <= 0 || n > MMF_POOL_MAX || B <= 0 || d <= 0 || (d & 7) || (lddy & 7) || lddy < n * d)
+    MMF_FAIL(MMF_E_SHAPE, "mmf_meanpool_cat_bwd: n=%d B=%d d=%d lddy=%d", n, B, d, lddy);
+  PoolArgs a = {};
+  a.n = n; a.B = B; a.d = d; a.ld = lddy;
+  int total = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!dxs[i] || Ts[i] <= 0 || !mmf_aligned16(dxs[i])) MMF_FAIL(MMF_E_SHAPE, "mmf_meanpool_cat_bwd[%d]: bad operand", i);
+    a.g[i] = static_cast<unsigned short*>(dxs[i]); a.T[i] = Ts[i];
+    a.blk_start[i] = total;
+    total += ew_grid((int64_t)B * Ts[i] * (d >> 3));
+  }
+  a.blk_start[n] = total;
+  hipLaunchKernelGGL(meanpool_cat_bwd_kernel, dim3(total), dim3(EW_THREADS), 0, static_cast<hipStream_t>(stream), a,
+                     static_cast<const unsigned short*>(dy));
+  MMF_CHECK_LAUNCH("mmf_meanpool_cat_bwd");
   return MMF_OK;
 }

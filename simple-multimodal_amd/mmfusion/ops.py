@@ -691,10 +691,17 @@ class _MeanPoolCat(torch.autograd.Function):
         n = len(xs)
         y = torch.empty((B, n * d), dtype=BF16, device=xs[0].device)
         L, st = lib.load(), lib.stream_ptr()
-        for i, x in enumerate(xs):
+        xs = [x.contiguous() for x in xs]
+        for x in xs:
             _req(x, BF16)
-            x = x.contiguous()
-            lib.check(L.mmf_meanpool_fwd(x.data_ptr(), y.data_ptr() + 2 * i * d, B, x.shape[1], d, n * d, st))
+        if n <= lib.POOL_MAX:                            # all modalities in one launch
+            import ctypes as C
+            ptrs = (C.c_void_p * n)(*[x.data_ptr() for x in xs])
+            Ts = (C.c_int * n)(*[x.shape[1] for x in xs])
+            lib.check(L.mmf_meanpool_cat_fwd(ptrs, Ts, n, y.data_ptr(), B, d, n * d, st))
+        else:
+            for i, x in enumerate(xs):
+                lib.check(L.mmf_meanpool_fwd(x.data_ptr(), y.data_ptr() + 2 * i * d, B, x.shape[1], d, n * d, st))
         ctx.shapes = [tuple(x.shape) for x in xs]
         return y
 
@@ -703,11 +710,16 @@ class _MeanPoolCat(torch.autograd.Function):
         g = g.contiguous()
         L, st = lib.load(), lib.stream_ptr()
         n = len(ctx.shapes)
-        out = []
-        for i, (B, T, d) in enumerate(ctx.shapes):
-            dx = torch.empty((B, T, d), dtype=BF16, device=g.device)
-            lib.check(L.mmf_meanpool_bwd(g.data_ptr() + 2 * i * d, dx.data_ptr(), B, T, d, n * d, st))
-            out.append(dx)
+        out = [torch.empty((B, T, d), dtype=BF16, device=g.device) for (B, T, d) in ctx.shapes]
+        B, _, d = ctx.shapes[0]
+        if n <= lib.POOL_MAX:
+            import ctypes as C
+            ptrs = (C.c_void_p * n)(*[o.data_ptr() for o in out])
+            Ts = (C.c_int * n)(*[sh[1] for sh in ctx.shapes])
+            lib.check(L.mmf_meanpool_cat_bwd(g.data_ptr(), ptrs, Ts, n, B, d, n * d, st))
+        else:
+            for i, (B, T, d) in enumerate(ctx.shapes):
+                lib.check(L.mmf_meanpool_bwd(g.data_ptr() + 2 * i * d, out[i].data_ptr(), B, T, d, n * d, st))
         return tuple(out)
 
 
