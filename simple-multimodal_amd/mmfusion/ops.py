@@ -338,7 +338,13 @@ class _GroupedLinear(torch.autograd.Function):
     """tensors = [x_0, res_0|None, w_0.p, b_0.p|None, x_1, ...]; returns one output per spec."""
 
     @staticmethod
-    def forward(ctx, specs: List[LinearSpec], out_f32: bool, *tensors):
+    def forward(ctx, specs: List[LinearSpec], out_f32, *tensors):
+        # out_f32 may be (out_f32, cat): with cat the outputs are the column blocks of ONE (M, sum N_i) tensor,
+        # which is returned instead of the list (torch.cat / torch.stack of the outputs without a copy, and one
+        # gradient tensor coming back instead of n slices)
+        cat = False
+        if isinstance(out_f32, tuple):
+            out_f32, cat = out_f32
         n = len(specs)
         relu = specs[0].relu
         has_bias = specs[0].b is not None
@@ -346,12 +352,23 @@ class _GroupedLinear(torch.autograd.Function):
         if any(s.relu != relu or (s.b is not None) != has_bias or s.has_residual != has_res for s in specs):
             raise ValueError("a linear group must share one epilogue")
         xs, ress, outs, probs = [], [], [], []
+        base, off = None, 0
+        if cat:
+            M0 = tensors[0].shape[0]
+            if any(tensors[4 * i].shape[0] != M0 for i in range(n)):
+                raise ValueError("a concatenated linear group needs equal row counts")
+            base = torch.empty((M0, sum(s.w.w16.shape[0] for s in specs)), dtype=torch.float32 if out_f32 else BF16,
+                               device=tensors[0].device)
         for i, s in enumerate(specs):
             x, res = tensors[4 * i], tensors[4 * i + 1]
             _req(x, BF16)
             w16 = s.w.w16
             bias = s.b.master if has_bias else None
-            y = torch.empty((x.shape[0], w16.shape[0]), dtype=torch.float32 if out_f32 else BF16, device=x.device)
+            if cat:
+                y = base[:, off:off + w16.shape[0]]
+                off += w16.shape[0]
+            else:
+                y = torch.empty((x.shape[0], w16.shape[0]), dtype=torch.float32 if out_f32 else BF16, device=x.device)
             probs.append((x, w16, y, bias, res))
             xs.append(x), ress.append(res), outs.append(y)
         epi = (EPI_BIAS if has_bias else 0) | (EPI_RELU if relu else 0) | (EPI_ADD_AUX if has_res else 0)
@@ -363,10 +380,10 @@ class _GroupedLinear(torch.autograd.Function):
                             for (x, w, y, b, _) in probs], epi, out_f32)
         else:
             gemm_group(GEMM_NT, probs, epi)
-        ctx.specs, ctx.out_f32 = specs, out_f32
-        ctx.save_for_backward(*xs, *(outs if relu else []))
+        ctx.specs, ctx.out_f32, ctx.cat = specs, out_f32, cat
+        ctx.save_for_backward(*xs, *(([base] if cat else outs) if relu else []))
         ctx.x_needs = [tensors[4 * i].requires_grad for i in range(n)]
-        return tuple(outs)
+        return base if cat else tuple(outs)
 
     @staticmethod
     def backward(ctx, *gys):
@@ -378,7 +395,25 @@ class _GroupedLinear(torch.autograd.Function):
         L = lib.load()
         st = lib.stream_ptr()
         dys = []
-        for i, g in enumerate(gys):
+        if ctx.cat:                                # one gradient for the concatenated output: slice it, no copies
+            g = gys[0]
+            if g is not None:
+                g = g.contiguous()
+                if g.dtype != BF16:
+                    g = cast_to_bf16(g)
+                if specs[0].relu:
+                    y = ys[0] if ys[0].dtype == BF16 else cast_to_bf16(ys[0])
+                    dz = torch.empty_like(g)
+                    lib.check(L.mmf_relu_bwd_bf16(g.data_ptr(), y.data_ptr(), dz.data_ptr(), g.numel(), st))
+                    g = dz
+            off = 0
+            for s in specs:
+                nout = s.w.w16.shape[0]
+                dys.append(None if g is None else g[:, off:off + nout])
+                off += nout
+            gys = dys
+        else:
+          for i, g in enumerate(gys):
             if g is None:
                 dys.append(None)
                 continue
@@ -416,13 +451,16 @@ class _GroupedLinear(torch.autograd.Function):
         return (None, None, *grads)
 
 
-def linear_group(items: Sequence[tuple], out_f32: bool = False) -> List[torch.Tensor]:
-    """items: (x_bf16 [M,K], LinearSpec, residual_bf16|None).  One NT launch for the group."""
+def linear_group(items: Sequence[tuple], out_f32: bool = False, cat: bool = False):
+    """items: (x_bf16 [M,K], LinearSpec, residual_bf16|None).  One NT launch for the group.  Returns the list of
+    outputs, or with ``cat`` ONE (M, sum N_i) tensor whose column blocks are the outputs (equal M required)."""
     specs, tensors = [], []
     for x, spec, res in items:
         spec.has_residual = res is not None
         specs.append(spec)
         tensors += [x, res, spec.w.p, spec.b.p if spec.b is not None else None]
+    if cat:
+        return _GroupedLinear.apply(specs, (out_f32, True), *tensors)
     return list(_GroupedLinear.apply(specs, out_f32, *tensors))
 
 

@@ -277,9 +277,8 @@ class MultimodalTransformer(_FusionBase):
         mhas = [self.text_self_attn, self.audio_self_attn, self.video_self_attn]
         att = _self_attention_core(mhas, [et, ea, ev], B, [Tt, Ta, Tv], p)
         pooled_att = ops.meanpool_cat([att[0].view(B, Tt, d), att[1].view(B, Ta, d), att[2].view(B, Tv, d)])
-        proj = ops.linear_group([(pooled_att[:, i * d:(i + 1) * d], _lin(m.out_proj), None)
-                                 for i, m in enumerate(mhas)], out_f32=True)    # (B, d) rows: f32 out is free
-        pf = torch.cat(proj, dim=-1)                                            # :171  (B, 3d) f32
+        pf = ops.linear_group([(pooled_att[:, i * d:(i + 1) * d], _lin(m.out_proj), None)
+                               for i, m in enumerate(mhas)], out_f32=True, cat=True)   # :171 (B, 3d) f32, written in place
         fused = ops.dropout(ops.linear(ops.to_bf16(pf), *_wb(self.final_fusion[0]), relu=True, out_f32=True),
                             p, True)                                            # :172
         return {"fused_features": fused, "text_features": pf[:, :d], "audio_features": pf[:, d:2 * d],
@@ -416,9 +415,9 @@ class AdaptiveFusion(_FusionBase):
         H, dh = mp.num_heads, mp.head_dim
         _, cat = _cat3(text_features, audio_features, video_features)                  # bf16 (B, 3d)
         xs = list(sops.split3(cat))
-        tr = ops.linear_group([(x, _lin(l), None) for x, l in
-                               zip(xs, (self.text_transform, self.audio_transform, self.video_transform))])
-        stacked = torch.stack(tr, dim=1).reshape(B * 3, d)                             # (B,3,d) :427-429
+        stacked = ops.linear_group([(x, _lin(l), None) for x, l in
+                                    zip(xs, (self.text_transform, self.audio_transform, self.video_transform))],
+                                   cat=True).view(B * 3, d)                            # (B,3,d) :427-429, no copy
         qkv = ops.linear(stacked, mp.qkv_spec().w, mp.qkv_spec().b)
         att = ops.attention_group([AttnSpec(B, 3, 3, q=(0, 0), k=(0, d), v=(0, 2 * d))], H, dh, [qkv], dropout_p=p)[0]
         attended = ops.linear(att, *_wb(mp.out_proj), out_f32=True).view(B, 3, d)
