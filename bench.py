@@ -305,6 +305,11 @@ def main():
             fwd_bwd()
             exchange()
             opt_launch()
+
+        def profile_step():            # rank 0's per-kernel timing pass: no collective (the other ranks are not in it)
+            before_replay()
+            fwd_bwd()
+            opt_launch()
         if use_graph:                       # two graphs: the all-reduce sits between backward and AdamW
             before_replay()
             graph = capture(fwd_bwd)
@@ -320,6 +325,7 @@ def main():
                 eager_step()
     else:
         eager_step = make_step(args.workload, model, xs, arena)
+        profile_step = eager_step
         if use_graph:
             graph = capture(eager_step)
 
@@ -357,7 +363,7 @@ def main():
     value = world * B * args.steps / elapsed
 
     if rank == 0:
-        prof = kernel_profile(eager_step, args.profile_steps)
+        prof = kernel_profile(profile_step, args.profile_steps)
         dom = max(prof, key=lambda k: prof[k]["ms_total"])
         dsec = prof[dom]["ms_total"] * 1e-3
         ach = prof[dom]["flops_total"] / dsec / 1e12

@@ -73,18 +73,29 @@ def allreduce_grads(arena, group=None, bucket_bytes: int = DEFAULT_BUCKET_BYTES,
     if wire is None or wire.numel() != arena.grads.numel():
         wire = torch.empty(arena.grads.numel(), dtype=torch.bfloat16, device=arena.grads.device)
         arena._wire_bf16 = wire
-    if arena.grads.is_cuda:
+    # Pipelined per bucket: narrow(b) -> all-reduce(b) [async, RCCL's stream] -> widen(b).  The narrowing of
+    # bucket b+1 runs on the compute stream while bucket b is on the wire, and bucket b is widened (and averaged,
+    # same kernel) while bucket b+1 is on the wire; only the first narrowing and the last widening are exposed.
+    gpu = arena.grads.is_cuda
+    if gpu:
         from . import lib
-        L, st = lib.load(), lib.stream_ptr()
-        lib.check(L.mmf_cast_f32_to_bf16(arena.grads.data_ptr(), wire.data_ptr(), wire.numel(), st))
-        allreduce_flat(wire, group, False, bucket_bytes)
-        lib.check(L.mmf_cast_bf16_to_f32_scaled(wire.data_ptr(), arena.grads.data_ptr(), wire.numel(), 1.0 / world,
-                                                lib.stream_ptr()))          # widen and average in one pass
-    else:                                   # CPU (gloo tests): same arithmetic with torch casts
-        wire.copy_(arena.grads)
-        allreduce_flat(wire, group, False, bucket_bytes)
-        arena.grads.copy_(wire)
-        arena.grads.mul_(1.0 / world)
+        L = lib.load()
+    bounds = bucket_bounds(wire.numel(), wire.element_size(), bucket_bytes)
+    pending = []
+    for s, e in bounds:
+        if gpu:
+            lib.check(L.mmf_cast_f32_to_bf16(arena.grads.data_ptr() + 4 * s, wire.data_ptr() + 2 * s, e - s, lib.stream_ptr()))
+        else:                               # CPU (gloo tests): same arithmetic with torch casts
+            wire[s:e].copy_(arena.grads[s:e])
+        pending.append((s, e, dist.all_reduce(wire[s:e], op=dist.ReduceOp.SUM, group=group, async_op=True)))
+    for s, e, work in pending:
+        work.wait()
+        if gpu:
+            lib.check(L.mmf_cast_bf16_to_f32_scaled(wire.data_ptr() + 2 * s, arena.grads.data_ptr() + 4 * s, e - s,
+                                                    1.0 / world, lib.stream_ptr()))     # widen and average in one pass
+        else:
+            arena.grads[s:e].copy_(wire[s:e])
+            arena.grads[s:e].mul_(1.0 / world)
 
 
 def broadcast_params(arena, src: int = 0, group=None) -> None:
