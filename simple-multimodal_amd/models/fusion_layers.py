@@ -277,8 +277,8 @@ class MultimodalTransformer(_FusionBase):
         mhas = [self.text_self_attn, self.audio_self_attn, self.video_self_attn]
         att = _self_attention_core(mhas, [et, ea, ev], B, [Tt, Ta, Tv], p)
         pooled_att = ops.meanpool_cat([att[0].view(B, Tt, d), att[1].view(B, Ta, d), att[2].view(B, Tv, d)])
-        pf = ops.linear_group([(pooled_att[:, i * d:(i + 1) * d], _lin(m.out_proj), None)
-                               for i, m in enumerate(mhas)], out_f32=True, cat=True)   # :171 (B, 3d) f32, written in place
+        pf = ops.linear_group([(x, _lin(m.out_proj), None) for x, m in zip(sops.split3(pooled_att), mhas)],
+                              out_f32=True, cat=True)                           # :171 (B, 3d) f32, written in place
         fused = ops.dropout(ops.linear(ops.to_bf16(pf), *_wb(self.final_fusion[0]), relu=True, out_f32=True),
                             p, True)                                            # :172
         return {"fused_features": fused, "text_features": pf[:, :d], "audio_features": pf[:, d:2 * d],
