@@ -210,6 +210,8 @@ int mmf_layernorm_bwd_grouped(const mmf_ln_problem* problems, int num_problems, 
 /* dst_bf16[i] = bf16(src_f32[i]); n multiple of 8 not required */
 int mmf_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 int mmf_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream);
+/* row-strided source (rows x cols, ld_src floats between rows) -> contiguous bf16; cols, ld_src multiples of 4 */
+int mmf_cast_f32_to_bf16_2d(const float* src, void* dst, int rows, int cols, int ld_src, void* stream);
 /* dst_f32[i] = scale * f32(src_bf16[i]): the receive side of the bf16-compressed gradient all-reduce
  * (mmfusion/dp.py: widen the summed wire buffer and divide by the world size in one pass) */
 int mmf_cast_bf16_to_f32_scaled(const void* src, float* dst, int64_t n, float scale, void* stream);

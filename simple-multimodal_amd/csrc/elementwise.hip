@@ -297,6 +297,19 @@ void meanpool_cat_bwd_kernel(const PoolArgs a, const unsigned short* __restrict_
   }
 }
 
+// row-strided f32 (rows x cols, ld_src floats between rows) -> contiguous bf16: the column blocks autograd hands back
+// from a torch.cat are cast without first being copied contiguous
+__global__ __launch_bounds__(EW_THREADS)
+void cast_f32_bf16_2d_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, int rows, int cols, int ld_src) {
+  const int cv = cols >> 2;
+  const int64_t nvec = (int64_t)rows * cv;
+  for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * EW_THREADS) {
+    const int r = (int)(i / cv), c = (int)(i % cv) * 4;
+    const f32x4_t a = *reinterpret_cast<const f32x4_t*>(src + (size_t)r * ld_src + c);
+    *reinterpret_cast<u32x2_t*>(dst + (size_t)r * cols + c) = u32x2_t{pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3])};
+  }
+}
+
 // zero up to MMF_ZERO_MAX_RANGES [start, end) float ranges of one buffer in ONE launch (the lazily-zeroed gradient
 // arena's unmanaged holes: biases, LayerNorm vectors, torch-produced gradients)
 struct ZeroArgs { float* base; int n; long long start[MMF_ZERO_MAX_RANGES]; long long end[MMF_ZERO_MAX_RANGES]; int blk_start[MMF_ZERO_MAX_RANGES + 1]; };
@@ -480,5 +493,15 @@ extern "C" int mmf_meanpool_cat_bwd(const void* dy, void* const* dxs, const int*
   hipLaunchKernelGGL(meanpool_cat_bwd_kernel, dim3(total), dim3(EW_THREADS), 0, static_cast<hipStream_t>(stream), a,
                      static_cast<const unsigned short*>(dy));
   MMF_CHECK_LAUNCH("mmf_meanpool_cat_bwd");
+  return MMF_OK;
+}
+
+extern "C" int mmf_cast_f32_to_bf16_2d(const float* src, void* dst, int rows, int cols, int ld_src, void* stream) {
+  if (rows <= 0 || cols <= 0) return MMF_OK;
+  if (!src || !dst || (cols & 3) || (ld_src & 3) || ld_src < cols || !mmf_aligned16(src) || (reinterpret_cast<uintptr_t>(dst) & 7))
+    MMF_FAIL(MMF_E_ALIGN, "mmf_cast_f32_to_bf16_2d: rows=%d cols=%d ld=%d (cols, ld multiples of 4; 16-byte aligned source)", rows, cols, ld_src);
+  hipLaunchKernelGGL(cast_f32_bf16_2d_kernel, dim3(ew_grid((int64_t)rows * (cols >> 2) / 4 + 1)), dim3(EW_THREADS), 0,
+                     static_cast<hipStream_t>(stream), src, static_cast<unsigned short*>(dst), rows, cols, ld_src);
+  MMF_CHECK_LAUNCH("mmf_cast_f32_to_bf16_2d");
   return MMF_OK;
 }

@@ -85,6 +85,13 @@ def _req(t: torch.Tensor, dtype) -> None:
 # --------------------------------------------------------------------------------------------
 def cast_to_bf16(x: torch.Tensor) -> torch.Tensor:
     _req(x, torch.float32)
+    if (x.dim() == 2 and not x.is_contiguous() and x.stride(1) == 1 and x.shape[1] % 4 == 0 and x.stride(0) % 4 == 0
+            and x.data_ptr() % 16 == 0):
+        # a column block of a wider tensor (what autograd returns for a torch.cat input): cast it where it lies
+        y = torch.empty(x.shape, dtype=BF16, device=x.device)
+        lib.check(lib.load().mmf_cast_f32_to_bf16_2d(x.data_ptr(), y.data_ptr(), x.shape[0], x.shape[1], x.stride(0),
+                                                     lib.stream_ptr()))
+        return y
     x = x.contiguous()
     y = torch.empty(x.shape, dtype=BF16, device=x.device)
     lib.check(lib.load().mmf_cast_f32_to_bf16(x.data_ptr(), y.data_ptr(), x.numel(), lib.stream_ptr()))
@@ -417,9 +424,7 @@ class _GroupedLinear(torch.autograd.Function):
             if g is None:
                 dys.append(None)
                 continue
-            g = g.contiguous()
-            if g.dtype != BF16:
-                g = cast_to_bf16(g)
+            g = cast_to_bf16(g) if g.dtype != BF16 else g.contiguous()      # (the cast takes row-strided sources)
             if specs[0].relu:                      # dz = dy * (y > 0)
                 y = ys[i] if ys[i].dtype == BF16 else cast_to_bf16(ys[i])
                 dz = torch.empty_like(g)

@@ -20,3 +20,26 @@ rows.sort(key=lambda e: -e.device_time_total)
 for e in rows[:45]:
     stack = " <- ".join(s.split("/")[-1] for s in e.stack[:3]) if e.stack else ""
     print(f"{e.key:32s} x{e.count:3d} {e.device_time_total:8.1f} us   {stack[:150]}")
+
+# where do the copies come from?  log every .contiguous() / .clone() that really copies, with its call site
+import collections, traceback
+sites = collections.Counter()
+_orig_contig, _orig_clone = torch.Tensor.contiguous, torch.Tensor.clone
+def _site():
+    for fr in reversed(traceback.extract_stack()[:-2]):
+        if "mmfusion" in fr.filename or "models" in fr.filename:
+            return f"{os.path.basename(fr.filename)}:{fr.lineno} {fr.line}"
+    return "?"
+def contig(self, *a, **k):
+    if self.is_cuda and not self.is_contiguous():
+        sites["contiguous " + str(tuple(self.shape)) + " " + _site()] += 1
+    return _orig_contig(self, *a, **k)
+def clone(self, *a, **k):
+    if self.is_cuda:
+        sites["clone " + str(tuple(self.shape)) + " " + _site()] += 1
+    return _orig_clone(self, *a, **k)
+torch.Tensor.contiguous, torch.Tensor.clone = contig, clone
+step(); torch.cuda.synchronize()
+torch.Tensor.contiguous, torch.Tensor.clone = _orig_contig, _orig_clone
+for k, v in sites.most_common(30):
+    print(f"x{v}  {k[:170]}")
