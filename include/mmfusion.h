@@ -290,6 +290,9 @@ int mmf_adaptive_combine_fwd(const float* hp, const float* W2, const float* b2, 
 int mmf_adaptive_combine_bwd(const float* hp, const float* W2, const float* attended, const float* aw,
                              const void* dweighted_bf16, const float* daw, float* dattended, float* dhp,
                              float* dW2, float* db2, int B, int d, void* stream);
+/* The head-averaged (B, 3, 3) attention weights AdaptiveFusion returns (:432-434; MultiheadAttention averages its
+ * weights over the heads): qkv bf16 [B*3][3 heads head_dim] packed q | k | v.  No gradient (inspection only). */
+int mmf_adaptive_attn_weights(const void* qkv_bf16, float* w, int B, int heads, int head_dim, void* stream);
 /* Narrow linear heads, 1 <= N <= 16 outputs, f32 masters (LateFusion :50-60, EmotionClassifier / valence /
  * arousal / uncertainty heads models/multimodal_model.py:56-60,186-219): y = x W^T + b.  dx may be NULL. */
 int mmf_linear_narrow_fwd(const float* x, const float* W, const float* b, float* y, int M, int N, int K, void* stream);

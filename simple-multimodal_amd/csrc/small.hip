@@ -397,6 +397,41 @@ void ada_bwd_kernel(const AdaArgs a) {
   }
 }
 
+// Head-averaged 3 x 3 attention weights of AdaptiveFusion's 3-token self-attention (reference :432-434 returns them
+// for inspection; nn.MultiheadAttention(need_weights=True) averages over heads): qkv bf16 [B*3][3 d] packed
+// (q | k | v), w[b][i][j] = mean_h softmax_j(q[b,i,h].k[b,j,h] / sqrt(dh)).  One workgroup per sample, no gradient.
+constexpr int ADAW_MAXH = 16;
+__global__ __launch_bounds__(SM_THREADS)
+void ada_attn_weights_kernel(const unsigned short* __restrict__ qkv, float* __restrict__ w, int H, int dh, float scale) {
+  __shared__ float sc[9 * ADAW_MAXH];
+  const int b = blockIdx.x, d = H * dh, tid = threadIdx.x;
+  if (tid < 9 * H) {
+    const int i = tid / (3 * H), j = (tid / H) % 3, h = tid % H;
+    const unsigned short* q = qkv + ((size_t)b * 3 + i) * 3 * d + h * dh;
+    const unsigned short* kk = qkv + ((size_t)b * 3 + j) * 3 * d + d + h * dh;
+    float s = 0.f;
+    for (int c = 0; c < dh; ++c) s += bf16_bits_to_f32(q[c]) * bf16_bits_to_f32(kk[c]);
+    sc[tid] = s * scale;
+  }
+  __syncthreads();
+  if (tid < 3 * H) {                                      // (i, h): softmax over j in place
+    const int i = tid / H, h = tid % H;
+    float e[3], mx = -3.0e38f, sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { e[j] = sc[(i * 3 + j) * H + h]; mx = fmaxf(mx, e[j]); }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { e[j] = __expf(e[j] - mx); sum += e[j]; }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) sc[(i * 3 + j) * H + h] = e[j] / sum;
+  }
+  __syncthreads();
+  if (tid < 9) {
+    float s = 0.f;
+    for (int h = 0; h < H; ++h) s += sc[tid * H + h];
+    w[(size_t)b * 9 + tid] = s / (float)H;
+  }
+}
+
 // ================================================================================================
 // Narrow linear heads, N <= 16 outputs (LateFusion's three d -> 7 classifiers :50-60, EmotionClassifier's last
 // layer and the valence / arousal / uncertainty heads, models/multimodal_model.py:56-60,186-219), f32 in / f32
@@ -659,5 +694,14 @@ extern "C" int mmf_rowmask_apply(const float* x, const float* mask, float* y, in
   const int grid = (int)((n + SM_THREADS - 1) / SM_THREADS < 2048 ? (n + SM_THREADS - 1) / SM_THREADS : 2048);
   hipLaunchKernelGGL(rowmask_kernel, dim3(grid), dim3(SM_THREADS), 0, static_cast<hipStream_t>(stream), x, mask, y, B, d);
   MMF_CHECK_LAUNCH("mmf_rowmask_apply");
+  return MMF_OK;
+}
+
+extern "C" int mmf_adaptive_attn_weights(const void* qkv_bf16, float* w, int B, int heads, int head_dim, void* stream) {
+  if (!qkv_bf16 || !w || B <= 0 || heads <= 0 || heads > ADAW_MAXH || head_dim <= 0)
+    MMF_FAIL(MMF_E_SHAPE, "mmf_adaptive_attn_weights: B=%d heads=%d (1..%d) head_dim=%d", B, heads, ADAW_MAXH, head_dim);
+  hipLaunchKernelGGL(ada_attn_weights_kernel, dim3(B), dim3(SM_THREADS), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const unsigned short*>(qkv_bf16), w, heads, head_dim, 1.f / sqrtf((float)head_dim));
+  MMF_CHECK_LAUNCH("mmf_adaptive_attn_weights");
   return MMF_OK;
 }

@@ -28,7 +28,7 @@ SYMBOLS = (
     "mmf_meanpool_fwd", "mmf_meanpool_bwd", "mmf_meanpool_cat_fwd", "mmf_meanpool_cat_bwd", "mmf_colsum_bf16", "mmf_colsum_grouped", "mmf_relu_bwd_bf16",
     "mmf_sqnorm_f32", "mmf_adamw_step", "mmf_skinny_linear_fwd", "mmf_skinny_linear_dgrad",
     "mmf_gat3_dense_fwd", "mmf_gat3_dense_bwd", "mmf_infonce_fwd", "mmf_infonce_bwd", "mmf_adaptive_combine_fwd",
-    "mmf_adaptive_combine_bwd", "mmf_linear_narrow_fwd", "mmf_linear_narrow_bwd", "mmf_stack3_embed_fwd",
+    "mmf_adaptive_combine_bwd", "mmf_adaptive_attn_weights", "mmf_linear_narrow_fwd", "mmf_linear_narrow_bwd", "mmf_stack3_embed_fwd",
     "mmf_stack3_embed_bwd", "mmf_rowmask_apply", "mmf_zero_ranges_f32",
 )
 
@@ -130,6 +130,7 @@ def load() -> C.CDLL:
     lib.mmf_infonce_bwd.argtypes = [P3, vp, vp, P3, P3, P3, i32, i32, f32, vp]
     lib.mmf_adaptive_combine_fwd.argtypes = [vp] * 6 + [i32, i32, vp]
     lib.mmf_adaptive_combine_bwd.argtypes = [vp] * 10 + [i32, i32, vp]
+    lib.mmf_adaptive_attn_weights.argtypes = [vp, vp, i32, i32, i32, vp]
     lib.mmf_linear_narrow_fwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp]
     lib.mmf_linear_narrow_bwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]
     lib.mmf_stack3_embed_fwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp]

@@ -421,10 +421,15 @@ class AdaptiveFusion(_FusionBase):
         qkv = ops.linear(stacked, mp.qkv_spec().w, mp.qkv_spec().b)
         att = ops.attention_group([AttnSpec(B, 3, 3, q=(0, 0), k=(0, d), v=(0, 2 * d))], H, dh, [qkv], dropout_p=p)[0]
         attended = ops.linear(att, *_wb(mp.out_proj), out_f32=True).view(B, 3, d)
-        with torch.no_grad():                      # head-averaged 3x3 weights, returned for inspection
-            q4 = qkv.detach().float().view(B, 3, 3, H, dh)
-            sc = torch.einsum("bihd,bjhd->bhij", q4[:, :, 0], q4[:, :, 1]) / math.sqrt(dh)
-            attn_w = F.softmax(sc, dim=-1).mean(dim=1)
+        attn_w = torch.empty((B, 3, 3), dtype=torch.float32, device=qkv.device)        # head-averaged weights, returned
+        if H <= 16:                                                                    # for inspection only (no gradient)
+            from mmfusion import lib as _lib
+            _lib.check(_lib.load().mmf_adaptive_attn_weights(qkv.data_ptr(), attn_w.data_ptr(), B, H, dh, _lib.stream_ptr()))
+        else:
+            with torch.no_grad():
+                q4 = qkv.detach().float().view(B, 3, 3, H, dh)
+                sc = torch.einsum("bihd,bjhd->bhij", q4[:, :, 0], q4[:, :, 1]) / math.sqrt(dh)
+                attn_w = F.softmax(sc, dim=-1).mean(dim=1)
         hp = ops.linear(cat, *_wb(self.weight_predictor[0]), relu=True, out_f32=True)
         # :436-443: d -> 3 logits, softmax, weighted sum of the attended modalities — one kernel (small.hip ada_*)
         weighted, aw = sops.adaptive_combine(hp, attended, self.weight_predictor[2].weight, self.weight_predictor[2].bias)
