@@ -105,8 +105,10 @@ int mmf_gemm_grouped_ex(const mmf_gemm_problem* problems, int num_problems, int 
                         int out_f32, const mmf_gemm_extra* extra, void* stream);
 
 /* Tuning hook: which kernel generation mmf_gemm_grouped dispatches to (0 automatic [default], 1 register-staged 128x128,
-* 2 LDS-DMA ring 256x128, 3 persistent LDS-DMA ring, 4 LDS-DMA ring 256x256).  Results are identical up to f32
- * summation order; exists so that A/B timings can be interleaved inside one process. */
+ * 2 LDS-DMA ring 256x128, 3 persistent LDS-DMA ring, 4 LDS-DMA ring 256x256, 5 NT-only 256x128 with a 32-deep k-step and
+ * two workgroups per CU [other layouts: 2]).  Automatic = 4 where the 256x256 tiling fills its CU rounds, else 5 for
+ * NT launches with K <= 1024, else 2.  Results are identical up to f32 summation order; exists so that A/B timings
+ * can be interleaved inside one process. */
 int mmf_gemm_select_impl(int impl);
 
 /* ------------------------------------------------------------------------------------------

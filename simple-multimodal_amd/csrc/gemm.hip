@@ -248,13 +248,15 @@ int mmf_gemm3_launch(const mmf_gemm_problem* problems, int num_problems, int lay
                      int out_f32, hipStream_t s);      // gemm3.hip: persistent LDS-DMA ring kernel
 int mmf_gemm4_launch(const mmf_gemm_problem* problems, int num_problems, int layout, int epilogue,
                      int out_f32, const mmf_gemm_extra* extra, hipStream_t s);   // gemm4.hip: 256x256 tile
+int mmf_gemm5_launch(const mmf_gemm_problem* problems, int num_problems, int layout, int epilogue,
+                     int out_f32, const mmf_gemm_extra* extra, hipStream_t s);   // gemm5.hip: NT, 32-deep k-step, 2 workgroups / CU
 
 // Implementation switch (A/B runs in one process: tools/gemm_bench.py): 0 = automatic (default), 1 =
 // register-staged 128x128 kernel of this file, 2 = 256x128 LDS-DMA ring (gemm2.hip), 3 = its persistent
 // form (gemm3.hip), 4 = 256x256 LDS-DMA ring (gemm4.hip).  Default from MMF_GEMM_IMPL, else automatic.
 static int g_gemm_impl = [] {
   const char* e = getenv("MMF_GEMM_IMPL");
-  return (e && e[0] >= '0' && e[0] <= '4') ? e[0] - '0' : 0;
+  return (e && e[0] >= '0' && e[0] <= '5') ? e[0] - '0' : 0;
 }();
 
 // Automatic choice between the two ring kernels.  The 256x256 tile does 25 % fewer LDS fragment reads,
@@ -262,17 +264,27 @@ static int g_gemm_impl = [] {
 // +22-26 % on the FFN1 / dH groups) but quantises coarser: it is used for NT / NN launches whose
 // 256x256 tiling fills at least 80 % of the CU-rounds it occupies.  wgrad (TN) stays on 256x128
 // (the transposed-read operands of the bigger wave tile do not fit 256 registers without spills).
+static const int g_shortk_mode = [] { const char* e = getenv("MMF_GEMM_SHORTK"); return e ? atoi(e) : 1; }();
 static int auto_impl(const mmf_gemm_problem* p, int n, int layout) {
   if (layout == MMF_GEMM_TN) return 2;
   long tiles = 0;
-  for (int i = 0; i < n; ++i) tiles += (long)((p[i].M + 255) / 256) * ((p[i].N + 255) / 256);
+  int kmax = 0;
+  for (int i = 0; i < n; ++i) {
+    tiles += (long)((p[i].M + 255) / 256) * ((p[i].N + 255) / 256);
+    kmax = p[i].K > kmax ? p[i].K : kmax;
+  }
   static const int cus = [] { int c = mmf_device_cu_count(); return c > 0 ? c : 256; }();
   const long rounds = (tiles + cus - 1) / cus;
-  return (tiles >= 2L * cus && tiles * 100 >= rounds * cus * 80) ? 4 : 2;
+  if (tiles >= 2L * cus && tiles * 100 >= rounds * cus * 80) return 4;
+  // NT launches with a short reduction that the 256x256 tiling does not fill: the 32-deep, two-workgroups-per-CU
+  // form of the 256x128 kernel (one workgroup's pipeline fill / output burst under the other's MFMA loop):
+  // +2 ... +9 % on the in-projection and out-projection launches of MulT (MMF_GEMM_SHORTK=0: off)
+  if (layout == MMF_GEMM_NT && g_shortk_mode && kmax <= 1024) return 5;
+  return 2;
 }
 static int gemm_impl() { return g_gemm_impl; }
 extern "C" int mmf_gemm_select_impl(int impl) {
-  if (impl < 0 || impl > 4) MMF_FAIL(MMF_E_UNSUPPORTED, "mmf_gemm_select_impl: %d not in 0..4", impl);
+  if (impl < 0 || impl > 5) MMF_FAIL(MMF_E_UNSUPPORTED, "mmf_gemm_select_impl: %d not in 0..5", impl);
   g_gemm_impl = impl;
   return MMF_OK;
 }
@@ -302,7 +314,7 @@ extern "C" int mmf_gemm_grouped_ex(const mmf_gemm_problem* problems, int num_pro
   }
   int impl = gemm_impl();
   if (impl == 0) impl = auto_impl(problems, num_problems, layout);
-  if (needs_v2 && impl != 4) impl = 2;             // only gemm2 / gemm4 have the alpha / dropout epilogue
+  if (needs_v2 && impl != 4 && impl != 5) impl = 2;   // only gemm2 / gemm4 / gemm5 have the alpha / dropout epilogue
   GemmArgs a;
   a.nprob = num_problems;
   a.epi = epilogue;
@@ -336,6 +348,10 @@ extern "C" int mmf_gemm_grouped_ex(const mmf_gemm_problem* problems, int num_pro
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (impl == 2) return mmf_gemm2_launch(problems, num_problems, layout, epilogue, out_f32, extra, s);
   if (impl == 4) return mmf_gemm4_launch(problems, num_problems, layout, epilogue, out_f32, extra, s);
+  if (impl == 5) {
+    if (layout == MMF_GEMM_NT) return mmf_gemm5_launch(problems, num_problems, layout, epilogue, out_f32, extra, s);
+    return mmf_gemm2_launch(problems, num_problems, layout, epilogue, out_f32, extra, s);
+  }
   if (impl == 3) {
     bool wide_ok = true;              // the persistent kernel only has the 16-byte bf16 epilogue
     for (int i = 0; i < num_problems && !out_f32; ++i)
