@@ -13,8 +13,8 @@ constexpr int SM_THREADS = 256;
 constexpr int SM_WAVES = SM_THREADS / 64;
 
 // Sum N per-thread partials over the workgroup; the totals land in red[0..N) (LDS, >= N floats) for every thread.
-template <int N>
-__device__ __forceinline__ void block_sum(float (&v)[N], float* red, float* scratch /* [SM_WAVES][N] */) {
+template <int N, int NW = SM_WAVES>
+__device__ __forceinline__ void block_sum(float (&v)[N], float* red, float* scratch /* [NW][N] */) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int i = 0; i < N; ++i) {
@@ -25,7 +25,7 @@ __device__ __forceinline__ void block_sum(float (&v)[N], float* red, float* scra
   if (threadIdx.x < N) {
     float s = 0.f;
 #pragma unroll
-    for (int w = 0; w < SM_WAVES; ++w) s += scratch[w * N + threadIdx.x];
+    for (int w = 0; w < NW; ++w) s += scratch[w * N + threadIdx.x];
     red[threadIdx.x] = s;
   }
   __syncthreads();
@@ -49,16 +49,18 @@ struct Gat3Args {
   float slope, inv_keep; unsigned drop_thresh, site; const unsigned long long* rng_state;
 };
 
+constexpr int GAT_THREADS = 512, GAT_WAVES = GAT_THREADS / 64;   // C = 768 columns: at most two per thread
+
 template <int H>
-__global__ __launch_bounds__(SM_THREADS)
+__global__ __launch_bounds__(GAT_THREADS)
 void gat3_fwd_kernel(const Gat3Args a) {
-  __shared__ float red[6 * H], scratch[SM_WAVES * 6 * H], alpha_s[9 * H];
+  __shared__ float red[6 * H], scratch[GAT_WAVES * 6 * H], alpha_s[9 * H];
   const int b = blockIdx.x, C = a.C, tid = threadIdx.x;
   const float* hb = a.h + (size_t)b * 3 * H * C;
   float part[6 * H];                                      // [src|dst][j][h]
 #pragma unroll
   for (int i = 0; i < 6 * H; ++i) part[i] = 0.f;
-  for (int c = tid; c < C; c += SM_THREADS) {
+  for (int c = tid; c < C; c += GAT_THREADS) {
 #pragma unroll
     for (int hh = 0; hh < H; ++hh) {
       const float as = a.att_src[hh * C + c], ad = a.att_dst[hh * C + c];
@@ -70,7 +72,7 @@ void gat3_fwd_kernel(const Gat3Args a) {
       }
     }
   }
-  block_sum<6 * H>(part, red, scratch);
+  block_sum<6 * H, GAT_WAVES>(part, red, scratch);
   if (tid < 6 * H) a.sdots[(size_t)b * 6 * H + tid] = red[tid];
   if (tid < 3 * H) {                                      // thread = (i, hh): softmax over the three sources j
     const int i = tid / H, hh = tid % H;
@@ -97,7 +99,7 @@ void gat3_fwd_kernel(const Gat3Args a) {
   }
   __syncthreads();
   const float invH = 1.f / H;
-  for (int c = tid; c < C; c += SM_THREADS) {
+  for (int c = tid; c < C; c += GAT_THREADS) {
     float hv[3 * H];
 #pragma unroll
     for (int q = 0; q < 3 * H; ++q) hv[q] = hb[q * C + c];
@@ -119,9 +121,9 @@ void gat3_fwd_kernel(const Gat3Args a) {
 }
 
 template <int H>
-__global__ __launch_bounds__(SM_THREADS)
+__global__ __launch_bounds__(GAT_THREADS)
 void gat3_bwd_kernel(const Gat3Args a) {
-  __shared__ float red[9 * H], scratch[SM_WAVES * 9 * H], alpha_d[9 * H], dssrc[3 * H], dsdst[3 * H];
+  __shared__ float red[9 * H], scratch[GAT_WAVES * 9 * H], alpha_d[9 * H], dssrc[3 * H], dsdst[3 * H];
   const int b = blockIdx.x, C = a.C, tid = threadIdx.x;
   const float* hb = a.h + (size_t)b * 3 * H * C;
   const float invH = 1.f / H;
@@ -135,7 +137,7 @@ void gat3_bwd_kernel(const Gat3Args a) {
   float part[9 * H];                                      // d(alpha_dropped)[i][j][h] = sum_c g[i,c]/H * h[j,h,c]
 #pragma unroll
   for (int q = 0; q < 9 * H; ++q) part[q] = 0.f;
-  for (int c = tid; c < C; c += SM_THREADS) {
+  for (int c = tid; c < C; c += GAT_THREADS) {
     float g[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) g[i] = grad_out(i, c) * invH;
@@ -148,7 +150,7 @@ void gat3_bwd_kernel(const Gat3Args a) {
         for (int i = 0; i < 3; ++i) part[(i * 3 + j) * H + hh] += g[i] * v;
       }
   }
-  block_sum<9 * H>(part, red, scratch);
+  block_sum<9 * H, GAT_WAVES>(part, red, scratch);
   if (tid < 3 * H) {                                      // thread = (i, hh): dropout, softmax and leaky-relu backward
     const int i = tid / H, hh = tid % H;
     const unsigned key = a.drop_thresh ? mmf_rng_key(*a.rng_state, a.site, (unsigned)b) : 0u;
@@ -180,7 +182,7 @@ void gat3_bwd_kernel(const Gat3Args a) {
     dsdst[n * H + hh] = d;                                // d s_dst[i = n]: sum over sources j
   }
   __syncthreads();
-  for (int c = tid; c < C; c += SM_THREADS) {
+  for (int c = tid; c < C; c += GAT_THREADS) {
     float g[3], gb = 0.f;
 #pragma unroll
     for (int i = 0; i < 3; ++i) { const float go = grad_out(i, c); gb += go; g[i] = go * invH; }
@@ -224,45 +226,62 @@ struct NceArgs {
 
 __device__ __forceinline__ void nce_pair(int p, int& ma, int& mb) { ma = p == 2 ? 1 : 0; mb = p == 0 ? 1 : 2; }
 
-// wave-wide dot product of two D-vectors (coalesced: lanes stride the columns)
-__device__ __forceinline__ float wave_dot(const float* __restrict__ x, const float* __restrict__ y, int D, int lane) {
-  float s = 0.f;
+constexpr int NCE_THREADS = 1024, NCE_WAVES = NCE_THREADS / 64;
+
+// Four similarities at once: x . y[j0 + u], u = 0..3 (rows past B are clamped; the caller ignores them).  The five
+// row segments of each column step are independent loads, so a wave has them in flight together instead of
+// walking a chain of L2 round trips (the first version of these kernels spent ~1,000 cycles per similarity).
+__device__ __forceinline__ void wave_dot4(const float* __restrict__ x, const float* __restrict__ y, int j0, int B, int D,
+                                          int lane, float (&out)[4]) {
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
   for (int c = lane * 4; c < D; c += 256) {
-    const f32x4_t u = *reinterpret_cast<const f32x4_t*>(x + c), v = *reinterpret_cast<const f32x4_t*>(y + c);
-    s += u[0] * v[0] + u[1] * v[1] + u[2] * v[2] + u[3] * v[3];
+    const f32x4_t u = *reinterpret_cast<const f32x4_t*>(x + c);
+    f32x4_t v[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) v[t] = *reinterpret_cast<const f32x4_t*>(y + (size_t)min(j0 + t, B - 1) * D + c);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] += u[0] * v[t][0] + u[1] * v[t][1] + u[2] * v[t][2] + u[3] * v[t][3];
   }
-  return wave_sum(s);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) out[t] = wave_sum(acc[t]);
 }
 
-// forward: one workgroup per pair p.  It normalises the two modalities of its pair (each modality is normalised
-// by two workgroups, writing identical values), then one WAVE per (i, j) similarity, then the row / column
-// log-sum-exps and the loss.
-__global__ __launch_bounds__(SM_THREADS)
+// forward: one 16-wave workgroup per pair p.  It normalises the two modalities of its pair (each modality is
+// normalised by two workgroups, writing identical values), then one wave per row of similarities, four at a time,
+// then the row / column log-sum-exps and the loss.
+__global__ __launch_bounds__(NCE_THREADS)
 void nce_fwd_kernel(const NceArgs a) {
   extern __shared__ float sim[];                          // [B][B]
   __shared__ float lsum;
   const int B = a.B, D = a.D, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p = blockIdx.x;
   int ma, mb; nce_pair(p, ma, mb);
-  for (int r = wave; r < 2 * B; r += SM_WAVES) {          // one wave per row: norm, then the normalised row
+  for (int r = wave; r < 2 * B; r += NCE_WAVES) {         // one wave per row: norm, then the normalised row
     const int m = r < B ? ma : mb, i = r < B ? r : r - B;
     const float* z = a.z[m] + (size_t)i * D;
     float ss = 0.f;
-    for (int c = lane; c < D; c += 64) ss += z[c] * z[c];
+    for (int c = lane * 4; c < D; c += 256) {
+      const f32x4_t v = *reinterpret_cast<const f32x4_t*>(z + c);
+      ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
     ss = wave_sum(ss);
     const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
     if (lane == 0) a.inv_norm[m * B + i] = inv;
     float* n = a.n[m] + (size_t)i * D;
-    for (int c = lane; c < D; c += 64) n[c] = z[c] * inv;
+    for (int c = lane * 4; c < D; c += 256)
+      *reinterpret_cast<f32x4_t*>(n + c) = *reinterpret_cast<const f32x4_t*>(z + c) * inv;
   }
   if (!a.losses) return;
   if (tid == 0) lsum = 0.f;
   __syncthreads();                                        // this workgroup's own writes of n are visible to it
-  for (int e = wave; e < B * B; e += SM_WAVES) {
-    const float s = wave_dot(a.n[ma] + (size_t)(e / B) * D, a.n[mb] + (size_t)(e % B) * D, D, lane);
-    if (lane == 0) sim[e] = s * a.inv_temp;
+  for (int i = wave; i < B; i += NCE_WAVES) {
+    for (int j0 = 0; j0 < B; j0 += 4) {
+      float s4[4];
+      wave_dot4(a.n[ma] + (size_t)i * D, a.n[mb], j0, B, D, lane, s4);
+      if (lane < 4 && j0 + lane < B) sim[i * B + j0 + lane] = s4[lane] * a.inv_temp;
+    }
   }
   __syncthreads();
-  for (int t = tid; t < 2 * B; t += SM_THREADS) {         // (row | col, i): log-sum-exp and the diagonal term
+  for (int t = tid; t < 2 * B; t += NCE_THREADS) {        // (row | col, i): log-sum-exp and the diagonal term
     const int col = t / B, i = t % B;
     float mx = -3.0e38f;
     for (int j = 0; j < B; ++j) mx = fmaxf(mx, col ? sim[j * B + i] : sim[i * B + j]);
@@ -276,48 +295,73 @@ void nce_fwd_kernel(const NceArgs a) {
   if (tid == 0) a.losses[p] = lsum;
 }
 
-// backward: workgroup (m, row block) computes dz_m for SM_WAVES rows.  It first rebuilds d loss / d sim of the
-// two pairs that contain modality m (one wave per similarity), then one wave per row: dn = dn_ext + sum over
-// the pairs of dsim . n_other (coalesced over the columns), and the projection of the normalisation.
-__global__ __launch_bounds__(SM_THREADS)
+// backward: 16-wave workgroup (m, block of 16 rows).  It first rebuilds d loss / d sim of the two pairs that contain
+// modality m (one wave per similarity row, four similarities at a time), then one wave per row of dz_m:
+// dn = dn_ext + sum over the pairs of dsim . n_other (float4 columns, four source rows in flight), and the
+// projection of the normalisation.
+__global__ __launch_bounds__(NCE_THREADS)
 void nce_bwd_kernel(const NceArgs a) {
   extern __shared__ float dsim[];                         // [2][B][B]: the two pairs of this modality, 1/T included
   const int B = a.B, D = a.D, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = blockIdx.x;
   int pairs[2], q = 0;
   for (int p = 0; p < 3; ++p) { int ma, mb; nce_pair(p, ma, mb); if (ma == m || mb == m) pairs[q++] = p; }
-  for (int e = wave; e < 2 * B * B; e += SM_WAVES) {
-    const int p = pairs[e / (B * B)], i = (e / B) % B, j = e % B;
-    float g = 0.f;
-    if (a.dloss[p]) {                                     // wave-uniform
-      int ma, mb; nce_pair(p, ma, mb);
-      const float s = wave_dot(a.n[ma] + (size_t)i * D, a.n[mb] + (size_t)j * D, D, lane) * a.inv_temp;
-      const float pr = __expf(s - a.lse[(p * 2 + 0) * B + i]), pc = __expf(s - a.lse[(p * 2 + 1) * B + j]);
-      g = *a.dloss[p] * (0.5f / B) * (pr + pc - (i == j ? 2.f : 0.f)) * a.inv_temp;
+  for (int u = wave; u < 2 * B; u += NCE_WAVES) {         // (pair k, row i of its first member)
+    const int k = u / B, i = u % B, p = pairs[k];
+    int ma, mb; nce_pair(p, ma, mb);
+    const bool live = a.dloss[p] != nullptr;              // wave-uniform
+    const float dl = live ? *a.dloss[p] * (0.5f / B) * a.inv_temp : 0.f;
+    const float lr = live ? a.lse[(p * 2 + 0) * B + i] : 0.f;
+    for (int j0 = 0; j0 < B; j0 += 4) {
+      float s4[4] = {0.f, 0.f, 0.f, 0.f};
+      if (live) wave_dot4(a.n[ma] + (size_t)i * D, a.n[mb], j0, B, D, lane, s4);
+      if (lane < 4 && j0 + lane < B) {
+        const int j = j0 + lane;
+        float g = 0.f;
+        if (live) {
+          const float s = s4[lane] * a.inv_temp;
+          g = dl * (__expf(s - lr) + __expf(s - a.lse[(p * 2 + 1) * B + j]) - (i == j ? 2.f : 0.f));
+        }
+        dsim[(k * B + i) * B + j] = g;
+      }
     }
-    if (lane == 0) dsim[e] = g;
   }
   __syncthreads();
-  const int i = blockIdx.y * SM_WAVES + wave;
+  const int i = blockIdx.y * NCE_WAVES + wave;
   if (i >= B) return;
   const float* n = a.n[m] + (size_t)i * D;
   float* dz = a.dz[m] + (size_t)i * D;
   float dot = 0.f;
-  for (int c = lane; c < D; c += 64) {
-    float g = a.dn[m] ? a.dn[m][(size_t)i * D + c] : 0.f;
+  for (int c = lane * 4; c < D; c += 256) {
+    f32x4_t g = a.dn[m] ? *reinterpret_cast<const f32x4_t*>(a.dn[m] + (size_t)i * D + c) : f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       int ma, mb; nce_pair(pairs[k], ma, mb);
-      const float* o = a.n[ma == m ? mb : ma];
+      const bool first = ma == m;                         // m is the pair's first member: weights are row i of dsim
+      const float* o = a.n[first ? mb : ma];
       const float* ds = dsim + k * B * B;
-      if (ma == m) { for (int j = 0; j < B; ++j) g += ds[i * B + j] * o[(size_t)j * D + c]; }
-      else         { for (int j = 0; j < B; ++j) g += ds[j * B + i] * o[(size_t)j * D + c]; }
+      for (int j0 = 0; j0 < B; j0 += 4) {
+        f32x4_t v[4];
+        float w[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int j = min(j0 + t, B - 1);
+          v[t] = *reinterpret_cast<const f32x4_t*>(o + (size_t)j * D + c);
+          w[t] = j0 + t < B ? (first ? ds[i * B + j] : ds[j * B + i]) : 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) g += v[t] * w[t];
+      }
     }
-    dz[c] = g;                                            // dn for now; projected below (same lane re-reads it)
-    dot += g * n[c];
+    *reinterpret_cast<f32x4_t*>(dz + c) = g;              // dn for now; projected below (same lane re-reads it)
+    const f32x4_t nv = *reinterpret_cast<const f32x4_t*>(n + c);
+    dot += g[0] * nv[0] + g[1] * nv[1] + g[2] * nv[2] + g[3] * nv[3];
   }
   dot = wave_sum(dot);
   const float inv = a.inv_norm[m * B + i];
-  for (int c = lane; c < D; c += 64) dz[c] = (dz[c] - n[c] * dot) * inv;
+  for (int c = lane * 4; c < D; c += 256) {
+    const f32x4_t g = *reinterpret_cast<const f32x4_t*>(dz + c), nv = *reinterpret_cast<const f32x4_t*>(n + c);
+    *reinterpret_cast<f32x4_t*>(dz + c) = (g - nv * dot) * inv;
+  }
 }
 
 // ================================================================================================
@@ -559,7 +603,7 @@ extern "C" int mmf_gat3_dense_fwd(const float* h, const float* att_src, const fl
   a.alpha = alpha; a.sdots = sdots;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (int rc = dispatch_heads(a.H, [&](auto Hc) {
-        hipLaunchKernelGGL((gat3_fwd_kernel<decltype(Hc)::value>), dim3(a.B), dim3(SM_THREADS), 0, s, a); })) return rc;
+        hipLaunchKernelGGL((gat3_fwd_kernel<decltype(Hc)::value>), dim3(a.B), dim3(GAT_THREADS), 0, s, a); })) return rc;
   MMF_CHECK_LAUNCH("mmf_gat3_dense_fwd");
   return MMF_OK;
 }
@@ -579,7 +623,7 @@ extern "C" int mmf_gat3_dense_bwd(const float* h, const float* att_src, const fl
   a.dh = dh; a.datt_src = datt_src; a.datt_dst = datt_dst; a.dbias = dbias;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (int rc = dispatch_heads(a.H, [&](auto Hc) {
-        hipLaunchKernelGGL((gat3_bwd_kernel<decltype(Hc)::value>), dim3(a.B), dim3(SM_THREADS), 0, s, a); })) return rc;
+        hipLaunchKernelGGL((gat3_bwd_kernel<decltype(Hc)::value>), dim3(a.B), dim3(GAT_THREADS), 0, s, a); })) return rc;
   MMF_CHECK_LAUNCH("mmf_gat3_dense_bwd");
   return MMF_OK;
 }
@@ -601,7 +645,7 @@ extern "C" int mmf_infonce_fwd(const float* const z[3], float* const n[3], float
   }
   if (!inv_norm || (losses && !lse)) MMF_FAIL(MMF_E_SHAPE, "mmf_infonce_fwd: null statistics buffer");
   a.inv_norm = inv_norm; a.losses = losses; a.lse = lse;
-  hipLaunchKernelGGL(nce_fwd_kernel, dim3(3), dim3(SM_THREADS), B * B * sizeof(float), static_cast<hipStream_t>(stream), a);
+  hipLaunchKernelGGL(nce_fwd_kernel, dim3(3), dim3(NCE_THREADS), B * B * sizeof(float), static_cast<hipStream_t>(stream), a);
   MMF_CHECK_LAUNCH("mmf_infonce_fwd");
   return MMF_OK;
 }
@@ -618,7 +662,7 @@ extern "C" int mmf_infonce_bwd(const float* const n[3], const float* inv_norm, c
   }
   if (!inv_norm || (any_loss && !lse)) MMF_FAIL(MMF_E_SHAPE, "mmf_infonce_bwd: null statistics buffer");
   a.inv_norm = const_cast<float*>(inv_norm); a.lse = const_cast<float*>(lse);
-  hipLaunchKernelGGL(nce_bwd_kernel, dim3(3, (B + SM_WAVES - 1) / SM_WAVES), dim3(SM_THREADS), 2 * B * B * sizeof(float),
+  hipLaunchKernelGGL(nce_bwd_kernel, dim3(3, (B + NCE_WAVES - 1) / NCE_WAVES), dim3(NCE_THREADS), 2 * B * B * sizeof(float),
                      static_cast<hipStream_t>(stream), a);
   MMF_CHECK_LAUNCH("mmf_infonce_bwd");
   return MMF_OK;
