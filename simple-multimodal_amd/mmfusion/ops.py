@@ -235,6 +235,18 @@ _callback_queued = False
 _pending_tiles = 0
 
 
+_branch_stream: Optional[torch.cuda.Stream] = None
+
+
+def branch_stream() -> torch.cuda.Stream:
+    """Second stream for work that runs beside the main chain (HierarchicalFusion's small branches).  The deferred
+    wgrad flush and anything else that consumes its results on the main stream joins it first."""
+    global _branch_stream
+    if _branch_stream is None:
+        _branch_stream = torch.cuda.Stream()
+    return _branch_stream
+
+
 def _issue_wgrad(pend: List[tuple]) -> None:
     # (has bias, overwrite) -> problems; overwrite = first wgrad of a lazily-zeroed step (arena.zero_grad(lazy=True))
     groups: dict = {}
@@ -263,6 +275,12 @@ def _flush_wgrad() -> None:
     global _pending_wgrad, _callback_queued, _pending_tiles
     pend, _pending_wgrad = _pending_wgrad, []
     _callback_queued, _pending_tiles = False, 0
+    if _branch_stream is not None:                       # operands queued by backward nodes that ran on the branch stream
+        cur = torch.cuda.current_stream()
+        cur.wait_stream(_branch_stream)
+        for q in pend:
+            q[0].record_stream(cur)
+            q[1].record_stream(cur)
     if _WGRAD_SIDE:
         if pend:
             _issue_wgrad_side(pend)

@@ -31,6 +31,8 @@ from mmfusion import small_ops as sops
 from mmfusion.ops import AttnSpec, LinearSpec, W
 
 _depth = 0          # >0 while inside an outer fusion forward: the arena was already ensured
+import os as _os
+_BRANCH_STREAM = _os.environ.get("MMF_HIER_STREAMS", "1") != "0"   # HierarchicalFusion: small branches beside MulT
 
 
 class _FusionBase(nn.Module):
@@ -74,6 +76,15 @@ def _as_rows(x: torch.Tensor) -> torch.Tensor:
     if not x.is_cuda:
         raise RuntimeError("mmfusion fusion layers run on the GPU only (no CPU fallback)")
     return ops.to_bf16(x.contiguous()).reshape(-1, x.shape[-1])
+
+
+def synth_flat(out) -> List[torch.Tensor]:
+    """Every tensor in a (nested) result dict."""
+    if isinstance(out, torch.Tensor):
+        return [out]
+    if isinstance(out, dict):
+        return [t for v in out.values() for t in synth_flat(v)]
+    return []
 
 
 _cat3_memo: Dict[tuple, Tuple[torch.Tensor, torch.Tensor]] = {}
@@ -466,11 +477,28 @@ class HierarchicalFusion(_FusionBase):
             d = text_features.shape[-1]
             pooled = ops.to_f32(ops.meanpool_cat([ops.to_bf16(x.contiguous()) for x in seq]))
             text_features, audio_features, video_features = pooled[:, :d], pooled[:, d:2 * d], pooled[:, 2 * d:]
-        early = self.early_fusion(text_features, audio_features, video_features)
-        mult = self.mult_fusion(*seq)
-        graph = self.graph_fusion(text_features, audio_features, video_features)
-        con = self.contrastive_fusion(text_features, audio_features, video_features, compute_contrastive_loss)
-        ada = self.adaptive_fusion(text_features, audio_features, video_features)
+        if _BRANCH_STREAM and text_features.is_cuda:
+            # The four (B, d)-row branches are ~100 latency-bound launches of a few workgroups each and are independent
+            # of the MulT branch: they run on a second stream beside MulT's chip-filling kernels (forward here; autograd
+            # replays each node's backward on its forward stream) and join before the meta MLP.
+            main, side = torch.cuda.current_stream(), ops.branch_stream()
+            _cat3(text_features, audio_features, video_features)        # shared cast issued before the fork
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                early = self.early_fusion(text_features, audio_features, video_features)
+                graph = self.graph_fusion(text_features, audio_features, video_features)
+                con = self.contrastive_fusion(text_features, audio_features, video_features, compute_contrastive_loss)
+                ada = self.adaptive_fusion(text_features, audio_features, video_features)
+            mult = self.mult_fusion(*seq)
+            main.wait_stream(side)
+            for t in [early, graph] + [v for dct in (con, ada) for v in synth_flat(dct)]:
+                t.record_stream(main)                                   # produced on `side`, consumed on `main` from here on
+        else:
+            early = self.early_fusion(text_features, audio_features, video_features)
+            mult = self.mult_fusion(*seq)
+            graph = self.graph_fusion(text_features, audio_features, video_features)
+            con = self.contrastive_fusion(text_features, audio_features, video_features, compute_contrastive_loss)
+            ada = self.adaptive_fusion(text_features, audio_features, video_features)
         allf = _as_rows(torch.cat([early, mult["fused_features"], graph, con["fused_features"],
                                    ada["fused_features"]], dim=-1))                    # :503-506
         h = ops.dropout(ops.linear(allf, *_wb(self.meta_fusion[0]), relu=True), p, True)
