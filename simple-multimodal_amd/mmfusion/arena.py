@@ -229,8 +229,8 @@ class ParamArena:
     def finalize_grads(self) -> None:
         """End of a lazily-zeroed backward: managed regions no wgrad wrote this step hold stale values."""
         from . import ops as _ops
-        if _ops._branch_stream is not None and self.grads.is_cuda:       # kernels of the branch stream write gradients too
-            torch.cuda.current_stream().wait_stream(_ops._branch_stream)
+        if self.grads.is_cuda:                       # kernels on the branch streams write gradients too
+            _ops.join_branch_streams()
         if self._lazy:
             for off in sorted(self._lazy):
                 self.grads[off:off + self._managed[off]].zero_()

@@ -235,16 +235,22 @@ _callback_queued = False
 _pending_tiles = 0
 
 
-_branch_stream: Optional[torch.cuda.Stream] = None
+_branch_streams: List[torch.cuda.Stream] = []
 
 
-def branch_stream() -> torch.cuda.Stream:
-    """Second stream for work that runs beside the main chain (HierarchicalFusion's small branches).  The deferred
-    wgrad flush and anything else that consumes its results on the main stream joins it first."""
-    global _branch_stream
-    if _branch_stream is None:
-        _branch_stream = torch.cuda.Stream()
-    return _branch_stream
+def branch_stream(i: int = 0) -> torch.cuda.Stream:
+    """Extra stream i for work that runs beside the main chain (HierarchicalFusion's small branches, the concurrent
+    halves of MulT's cross blocks).  The deferred wgrad flush and anything else that consumes its results on the
+    main stream joins every branch stream first (``join_branch_streams``)."""
+    while len(_branch_streams) <= i:
+        _branch_streams.append(torch.cuda.Stream())
+    return _branch_streams[i]
+
+
+def join_branch_streams() -> None:
+    cur = torch.cuda.current_stream()
+    for s in _branch_streams:
+        cur.wait_stream(s)
 
 
 def _issue_wgrad(pend: List[tuple]) -> None:
@@ -275,9 +281,9 @@ def _flush_wgrad() -> None:
     global _pending_wgrad, _callback_queued, _pending_tiles
     pend, _pending_wgrad = _pending_wgrad, []
     _callback_queued, _pending_tiles = False, 0
-    if _branch_stream is not None:                       # operands queued by backward nodes that ran on the branch stream
+    if _branch_streams:                                  # operands queued by backward nodes that ran on a branch stream
         cur = torch.cuda.current_stream()
-        cur.wait_stream(_branch_stream)
+        join_branch_streams()
         for q in pend:
             q[0].record_stream(cur)
             q[1].record_stream(cur)

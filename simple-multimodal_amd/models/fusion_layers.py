@@ -33,6 +33,7 @@ from mmfusion.ops import AttnSpec, LinearSpec, W
 _depth = 0          # >0 while inside an outer fusion forward: the arena was already ensured
 import os as _os
 _BRANCH_STREAM = _os.environ.get("MMF_HIER_STREAMS", "1") != "0"   # HierarchicalFusion: small branches beside MulT
+_MULT_STREAMS = int(_os.environ.get("MMF_MULT_STREAMS", "2"))       # MulT's cross blocks as this many concurrent groups (1, 2, 3)
 
 
 class _FusionBase(nn.Module):
@@ -277,9 +278,37 @@ class MultimodalTransformer(_FusionBase):
         t, a, v = _as_rows(text_features), _as_rows(audio_features), _as_rows(video_features)
         blocks = [self.text_to_audio, self.text_to_video, self.audio_to_text, self.audio_to_video,
                   self.video_to_text, self.video_to_audio]
-        t_a, t_v, a_t, a_v, v_t, v_a = _cross_blocks(
-            blocks, [t, t, a, a, v, v], [a, v, t, v, t, a], B, [Tt, Tt, Ta, Ta, Tv, Tv],
-            [Ta, Tv, Tt, Tv, Tt, Ta], p)                                        # :146-153
+        qs, kvs, Tqs, Tks = [t, t, a, a, v, v], [a, v, t, v, t, a], [Tt, Tt, Ta, Ta, Tv, Tv], [Ta, Tv, Tt, Tv, Tt, Ta]
+        if _MULT_STREAMS > 1 and _depth == 1 and t.is_cuda:      # as the root module only: nested in HierarchicalFusion the
+            # branch stream already fills the holes, and a third stream measured slower (hier-seq 2.90 -> 3.24 ms)
+            # The six blocks are independent: as balanced groups on concurrent streams, one group's HBM- / latency-bound
+            # launches (attention, LayerNorm, residual adds, the partly filled last round of every GEMM launch) run
+            # beside another group's GEMMs.  Forward here; autograd replays each node's backward on its forward stream.
+            groups = {2: ([0, 3, 4], [1, 2, 5]),           # {t<-a, a<-v, v<-t} / {t<-v, a<-t, v<-a}: one query size each
+                      3: ([0, 4], [1, 5], [2, 3])}[_MULT_STREAMS]
+            main = torch.cuda.current_stream()
+            outs = [None] * 6
+            sides = []
+            for gi, g in enumerate(groups[1:]):
+                side = ops.branch_stream(1 + gi)           # stream 0 belongs to HierarchicalFusion's small branches
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    r = _cross_blocks([blocks[i] for i in g], [qs[i] for i in g], [kvs[i] for i in g], B,
+                                      [Tqs[i] for i in g], [Tks[i] for i in g], p)
+                for i, x in zip(g, r):
+                    outs[i] = x
+                sides.append((side, g))
+            g = groups[0]
+            for i, x in zip(g, _cross_blocks([blocks[i] for i in g], [qs[i] for i in g], [kvs[i] for i in g], B,
+                                             [Tqs[i] for i in g], [Tks[i] for i in g], p)):
+                outs[i] = x
+            for side, g in sides:
+                main.wait_stream(side)
+                for i in g:
+                    outs[i].record_stream(main)
+            t_a, t_v, a_t, a_v, v_t, v_a = outs
+        else:
+            t_a, t_v, a_t, a_v, v_t, v_a = _cross_blocks(blocks, qs, kvs, B, Tqs, Tks, p)    # :146-153
         et, ea, ev = ops.add3(t, t_a, t_v), ops.add3(a, a_t, a_v), ops.add3(v, v_t, v_a)   # :156-158
         # :161-168.  The self-attention outputs are only ever used through their mean over T, and the
         # out-projection is affine, so mean_t(out_proj(o_t)) == out_proj(mean_t o_t): pool the attention
