@@ -364,6 +364,12 @@ def main():
     value = world * B * args.steps / elapsed
 
     if rank == 0:
+        # per-kernel HIP-event timing runs with the stream concurrency of the timed steps switched off (MulT's two
+        # block groups, HierarchicalFusion's branch stream): a kernel that shares the chip with another stream's
+        # kernel would be charged the other's time.  The dominant kernel (the deferred wgrad launch) runs after the
+        # join either way, so its duration is the same in both modes (and in the rocprofv3 summary).
+        from models import fusion_layers as _fl
+        _fl._MULT_STREAMS, _fl._BRANCH_STREAM = 1, False
         prof = kernel_profile(profile_step, args.profile_steps)
         dom = max(prof, key=lambda k: prof[k]["ms_total"])
         dsec = prof[dom]["ms_total"] * 1e-3
