@@ -7,7 +7,7 @@
 
 Workload (BASELINE.json configs[1]): MulT cross-modal attention,
 bf16 storage / f32 accumulate, synthetic features text (16,512,768), audio (16,400,768),
-video (16,30,768) ~ N(0,1) from seed 1234+rank, default-initialised weights from
+video (16,30,768) ~ N(0,1) from seed 1234+rank (generated in fp32, cast to bf16 once at set-up), default-initialised weights from
 torch.manual_seed(0), fusion_dropout = 0, loss = fused_features.sum().
 
 One "step" = fp32->bf16 weight-shadow cast, gradient-arena zeroing, forward, backward — and, for
@@ -74,8 +74,10 @@ def build(workload, device, rank, dropout=0.0):
     else:
         model = (fl.MultimodalTransformer if workload == "mult" else fl.HierarchicalFusion)(cfg)
     model = model.to(device).train()
-    xs = [t.to(device) for t in synth.make_features(S["B"], (S["T_text"], S["T_audio"], S["T_frames"]), S["d"],
-                                                    seed=synth.INPUT_SEED + rank)]
+    # features ~ N(0,1) generated in fp32 from the seed, then cast to bf16 — once, here: the
+    # step's inputs are the bf16 tensors resident in HBM
+    xs = [t.to(device).to(torch.bfloat16) for t in synth.make_features(S["B"], (S["T_text"], S["T_audio"], S["T_frames"]),
+                                                                     S["d"], seed=synth.INPUT_SEED + rank)]
     return cfg, model, xs
 
 
