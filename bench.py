@@ -181,11 +181,14 @@ def cpu_baseline(workload):
                       f"steps ({best:.2f} s/step) on {model_name}"}
 
 
-_SYMBOL = {"gemm_grouped_kernel<NT,bf16>": ["gemm4_grouped_kernel<false, false, false>", "gemm2_grouped_kernel<false, false, false>",
-                                            "gemm5_grouped_kernel<false>"],
-           "gemm_grouped_kernel<NT,f32>": ["gemm2_grouped_kernel<false, false, true>"],
-           "gemm_grouped_kernel<NN,bf16>": ["gemm4_grouped_kernel<false, true, false>", "gemm2_grouped_kernel<false, true, false>"],
-           "gemm_grouped_kernel<TN,f32>": ["gemm2_grouped_kernel<true, true, true>"],
+_SYMBOL = {"gemm4_grouped_kernel<NT,bf16>": ["gemm4_grouped_kernel<false, false, false>"],
+           "gemm2_grouped_kernel<NT,bf16>": ["gemm2_grouped_kernel<false, false, false>"],
+           "gemm5_grouped_kernel<NT,bf16>": ["gemm5_grouped_kernel<false>"],
+           "gemm2_grouped_kernel<NT,f32>": ["gemm2_grouped_kernel<false, false, true>"],
+           "gemm5_grouped_kernel<NT,f32>": ["gemm5_grouped_kernel<true>"],
+           "gemm4_grouped_kernel<NN,bf16>": ["gemm4_grouped_kernel<false, true, false>"],
+           "gemm2_grouped_kernel<NN,bf16>": ["gemm2_grouped_kernel<false, true, false>"],
+           "gemm2_grouped_kernel<TN,f32>": ["gemm2_grouped_kernel<true, true, true>"],
            "attn_fwd_kernel<96>": ["attn_fwd2_kernel<96, false>"],
            "attn_bwd_kernels<96>": ["attn_bwd_dq2_kernel<96, false>", "attn_bwd_dkv2_kernel<96, false>"]}
 

@@ -110,6 +110,8 @@ int mmf_gemm_grouped_ex(const mmf_gemm_problem* problems, int num_problems, int 
  * NT launches with K <= 1024, else 2.  Results are identical up to f32 summation order; exists so that A/B timings
  * can be interleaved inside one process. */
 int mmf_gemm_select_impl(int impl);
+/* the kernel generation the calling thread's last mmf_gemm_grouped[_ex] call dispatched to (profiling labels) */
+int mmf_gemm_last_impl(void);
 
 /* ------------------------------------------------------------------------------------------
  * Skinny-M linear layers (1 <= M <= 64 rows): the (B, d) MLPs of the Early / Contrastive / Adaptive /

@@ -283,6 +283,8 @@ static int auto_impl(const mmf_gemm_problem* p, int n, int layout) {
   return 2;
 }
 static int gemm_impl() { return g_gemm_impl; }
+static thread_local int t_last_impl = 0;
+extern "C" int mmf_gemm_last_impl(void) { return t_last_impl; }
 extern "C" int mmf_gemm_select_impl(int impl) {
   if (impl < 0 || impl > 5) MMF_FAIL(MMF_E_UNSUPPORTED, "mmf_gemm_select_impl: %d not in 0..5", impl);
   g_gemm_impl = impl;
@@ -315,6 +317,8 @@ extern "C" int mmf_gemm_grouped_ex(const mmf_gemm_problem* problems, int num_pro
   int impl = gemm_impl();
   if (impl == 0) impl = auto_impl(problems, num_problems, layout);
   if (needs_v2 && impl != 4 && impl != 5) impl = 2;   // only gemm2 / gemm4 / gemm5 have the alpha / dropout epilogue
+  if (impl == 5 && layout != MMF_GEMM_NT) impl = 2;
+  t_last_impl = impl;
   GemmArgs a;
   a.nprob = num_problems;
   a.epi = epilogue;

@@ -21,7 +21,7 @@ GEMM_MAX_PROBLEMS, ATTN_MAX_PROBLEMS, LN_MAX_PROBLEMS, COLSUM_MAX_PROBLEMS = 24,
 
 # every symbol include/mmfusion.h declares (tests check the .so exports all of them)
 SYMBOLS = (
-    "mmf_version", "mmf_last_error", "mmf_device_cu_count", "mmf_gemm_grouped", "mmf_gemm_grouped_ex", "mmf_gemm_select_impl",
+    "mmf_version", "mmf_last_error", "mmf_device_cu_count", "mmf_gemm_grouped", "mmf_gemm_grouped_ex", "mmf_gemm_select_impl", "mmf_gemm_last_impl",
     "mmf_attn_fwd_grouped_ex", "mmf_attn_bwd_grouped_ex", "mmf_dropout", "mmf_attn_select_impl",
     "mmf_attn_fwd_grouped", "mmf_attn_bwd_grouped", "mmf_layernorm_fwd_grouped",
     "mmf_layernorm_bwd_grouped", "mmf_layernorm_bwd_workspace_bytes", "mmf_cast_f32_to_bf16", "mmf_cast_bf16_to_f32", "mmf_cast_bf16_to_f32_scaled", "mmf_cast_f32_to_bf16_2d", "mmf_add3_bf16",
@@ -190,12 +190,14 @@ def gemm_grouped(problems: Sequence[GemmProblem], layout: int, epilogue: int, ou
     arr = (GemmProblem * len(problems))(*problems)
     flops = sum(2.0 * p.M * p.N * p.K for p in problems) if PROFILE is not None else 0.0
     detail = [(p.M, p.N, p.K) for p in problems] if PROFILE is not None else None
-    with _Timed(f"gemm_grouped_kernel<{_LAYOUT_NAME[layout]},{'f32' if out_f32 else 'bf16'}>", flops, detail):
+    with _Timed(f"gemm_grouped_kernel<{_LAYOUT_NAME[layout]},{'f32' if out_f32 else 'bf16'}>", flops, detail) as tm:
         if alpha == 1.0 and not (epilogue & EPI_DROPOUT):
             check(load().mmf_gemm_grouped(arr, len(problems), layout, epilogue, int(out_f32), stream_ptr()))
         else:
             ex = GemmExtra(alpha, dropout_p, rng_state_ptr, site)
             check(load().mmf_gemm_grouped_ex(arr, len(problems), layout, epilogue, int(out_f32), C.byref(ex), stream_ptr()))
+        if PROFILE is not None:            # name the kernel generation that ran: the dominant kernel is a kernel symbol
+            tm.label = f"gemm{load().mmf_gemm_last_impl()}_grouped_kernel<{_LAYOUT_NAME[layout]},{'f32' if out_f32 else 'bf16'}>"
 
 
 def attn_fwd_grouped(problems: Sequence[AttnProblem], head_dim: int, scale: float, dropout_p: float = 0.0,
