@@ -61,7 +61,7 @@ int mmf_device_cu_count(void);
  * aux is bf16 with leading dimension ldaux.  Output is bf16 or f32 (out_f32 != 0).
  * One launch covers all problems (<= MMF_GEMM_MAX_PROBLEMS); problems must not alias outputs.
  * ------------------------------------------------------------------------------------------ */
-#define MMF_GEMM_MAX_PROBLEMS 24
+#define MMF_GEMM_MAX_PROBLEMS 48
 enum { MMF_GEMM_NT = 0, MMF_GEMM_NN = 1, MMF_GEMM_TN = 2 };
 enum {
   MMF_EPI_BIAS = 1,

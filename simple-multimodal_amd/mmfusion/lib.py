@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libmmfusion.so")
 
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 EPI_BIAS, EPI_RELU, EPI_MASK_AUX, EPI_ADD_AUX, EPI_ACCUM, EPI_COLSUM_A, EPI_DROPOUT = 1, 2, 4, 8, 16, 32, 64
-GEMM_MAX_PROBLEMS, ATTN_MAX_PROBLEMS, LN_MAX_PROBLEMS, COLSUM_MAX_PROBLEMS = 24, 12, 8, 24
+GEMM_MAX_PROBLEMS, ATTN_MAX_PROBLEMS, LN_MAX_PROBLEMS, COLSUM_MAX_PROBLEMS = 48, 12, 8, 24
 
 # every symbol include/mmfusion.h declares (tests check the .so exports all of them)
 SYMBOLS = (

@@ -253,14 +253,21 @@ def join_branch_streams() -> None:
         cur.wait_stream(s)
 
 
+_WGRAD_SORT = _os.environ.get("MMF_WGRAD_SORT", "k")
+
+
 def _issue_wgrad(pend: List[tuple]) -> None:
     # (has bias, overwrite) -> problems; overwrite = first wgrad of a lazily-zeroed step (arena.zero_grad(lazy=True))
     groups: dict = {}
     for q in pend:
         groups.setdefault((q[3] is not None, q[5]), []).append(q[:5])
-    # big problems first: the tail of the launch is then made of small tiles
+    # longest tiles first (a tile's duration goes with K = the rows of dy), big outputs first among equals: the
+    # kernel hands tiles to the CUs in this order, so the tail of the launch is made of the short tiles
     for (has_bias, overwrite), group in sorted(groups.items(), key=lambda kv: (not kv[0][0], not kv[0][1])):
-        group.sort(key=lambda t: -(t[2].shape[0] * t[2].shape[1] * t[0].shape[0]))
+        if _WGRAD_SORT == "k":
+            group.sort(key=lambda t: (-t[0].shape[0], -(t[2].shape[0] * t[2].shape[1])))
+        else:
+            group.sort(key=lambda t: -(t[2].shape[0] * t[2].shape[1] * t[0].shape[0]))
         gemm_group(GEMM_TN, group, (0 if overwrite else EPI_ACCUM) | (EPI_COLSUM_A if has_bias else 0))
 
 
