@@ -14,8 +14,8 @@
 //             1-KiB piece fetches global chunk s ^ f(r) of the same row, i.e. coalescing is unchanged;
 //   bounds    buffer descriptors: rows/columns past the matrix give an out-of-range offset, the
 //             hardware range check returns zeros into LDS;
-//   order     tile ids are remapped so that each XCD (blockIdx % 8) walks a contiguous range of
-//             tiles: neighbours share the B panel in that XCD's L2 (guide T1, bijective form);
+//   order     tiles go to the XCDs (blockIdx % 8) in granules of 32 consecutive ids (mmf_xcd_tile): neighbours
+//             share A/B panels in that XCD's L2 and every XCD gets the same mix of long and short tiles;
 //   db        wgrad's fused bias gradient is one extra MFMA per (k-substep, m-tile) against an
 //             all-ones fragment — no extra LDS or HBM traffic.
 #include "mmf_internal.h"
@@ -34,7 +34,7 @@ constexpr unsigned OOB = 0x80000000u;
 struct GemmArgs {
   int nprob;
   int epi;
-  int xcd_granule;                   // 0: each XCD walks one contiguous range of tiles; G: ranges of G tiles dealt round-robin
+  int xcd_granule;                   // mmf_xcd_tile()
   float alpha;                       // multiplies the result after the mask step
   unsigned drop_thresh, site;        // MMF_EPI_DROPOUT
   const unsigned long long* rng_state;
@@ -109,27 +109,7 @@ __global__ __launch_bounds__(NTHREADS, 2)
 void gemm2_grouped_kernel(const GemmArgs args, const int total_tiles) {
   __shared__ __attribute__((aligned(1024))) char smem[STAGES * STAGE_BYTES];
 
-  // ---- XCD-aware tile id --------------------------------------------------------------------------
-  // The dispatcher deals workgroups to the 8 XCDs round-robin (blockIdx % 8), so XCD x runs ids x, x+8, ...
-  // Tiles are handed out in GRANULES of G consecutive tile ids, granule g to XCD g % 8: the ~32 tiles an XCD
-  // runs at one time are still neighbours (they share A/B panels in that XCD's L2), and every XCD gets the
-  // same mix of problems.  The host orders problems by per-tile duration (K) descending; one contiguous range
-  // per XCD (the earlier mapping, granule 0) then gave XCD 0 only the longest tiles and XCD 7 the shortest —
-  // a grouped wgrad launch with K = 8192 / 6400 / 480 finished when XCD 0 did.  The last (< 8 G) tiles, and
-  // launches smaller than that, keep one contiguous range per XCD.
-  int bid;
-  {
-    const int orig = blockIdx.x, xcd = orig & 7;
-    const int G = args.xcd_granule;
-    const int full = G > 0 ? (total_tiles / (8 * G)) * (8 * G) : 0;
-    if (orig < full) {
-      const int j = orig >> 3;
-      bid = ((j / G) * 8 + xcd) * G + (j % G);
-    } else {
-      const int rest = total_tiles - full, q = rest >> 3, r = rest & 7;
-      bid = full + (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + ((orig - full) >> 3);
-    }
-  }
+  const int bid = mmf_xcd_tile(blockIdx.x, total_tiles, args.xcd_granule);   // balanced tile -> XCD map (mmf_internal.h)
   int pi = 0;
   while (pi + 1 < args.nprob && bid >= args.tile_start[pi + 1]) ++pi;
   const mmf_gemm_problem& P = args.p[pi];
@@ -379,8 +359,7 @@ int mmf_gemm2_launch(const mmf_gemm_problem* problems, int num_problems, int lay
   GemmArgs a;
   a.nprob = num_problems;
   a.epi = epilogue;
-  static const int granule = [] { const char* e = getenv("MMF_GEMM_XCD_GRANULE"); return e ? atoi(e) : 32; }();
-  a.xcd_granule = granule > 0 ? granule : 0;
+  a.xcd_granule = mmf_xcd_granule();
   a.alpha = extra ? extra->alpha : 1.f;
   a.drop_thresh = extra ? mmf_drop_thresh(extra->dropout_p) : 0u;
   a.site = extra ? extra->site : 0u;

@@ -17,8 +17,7 @@
 //             1-KiB piece fetches global chunk s ^ f(r) of the same row, i.e. coalescing is unchanged;
 //   bounds    buffer descriptors: rows/columns past the matrix give an out-of-range offset, the
 //             hardware range check returns zeros into LDS;
-//   order     tile ids are remapped so that each XCD (blockIdx % 8) walks a contiguous range of
-//             tiles: neighbours share the B panel in that XCD's L2 (guide T1, bijective form);
+//   order     tiles go to the XCDs in granules of 32 consecutive ids (mmf_xcd_tile, mmf_internal.h);
 //   db        wgrad's fused bias gradient is one extra MFMA per (k-substep, m-tile) against an
 //             all-ones fragment — no extra LDS or HBM traffic.
 #include "mmf_internal.h"
@@ -37,6 +36,7 @@ constexpr unsigned OOB = 0x80000000u;
 struct GemmArgs {
   int nprob;
   int epi;
+  int xcd_granule;                   // mmf_xcd_tile()
   float alpha;                       // multiplies the result after the mask step
   unsigned drop_thresh, site;        // MMF_EPI_DROPOUT
   const unsigned long long* rng_state;
@@ -111,12 +111,7 @@ __global__ __launch_bounds__(NTHREADS, 2)
 void gemm4_grouped_kernel(const GemmArgs args, const int total_tiles) {
   __shared__ __attribute__((aligned(1024))) char smem[STAGES * STAGE_BYTES];
 
-  // ---- XCD-aware tile id: XCD x (= blockIdx % 8) walks a contiguous range of tiles ----------------
-  int bid;
-  {
-    const int orig = blockIdx.x, xcd = orig & 7, q = total_tiles >> 3, r = total_tiles & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-  }
+  const int bid = mmf_xcd_tile(blockIdx.x, total_tiles, args.xcd_granule);   // balanced tile -> XCD map (mmf_internal.h)
   int pi = 0;
   while (pi + 1 < args.nprob && bid >= args.tile_start[pi + 1]) ++pi;
   const mmf_gemm_problem& P = args.p[pi];
@@ -348,6 +343,7 @@ int mmf_gemm4_launch(const mmf_gemm_problem* problems, int num_problems, int lay
   GemmArgs a;
   a.nprob = num_problems;
   a.epi = epilogue;
+  a.xcd_granule = mmf_xcd_granule();
   a.alpha = extra ? extra->alpha : 1.f;
   a.drop_thresh = extra ? mmf_drop_thresh(extra->dropout_p) : 0u;
   a.site = extra ? extra->site : 0u;

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <stdarg.h>
 #include "../../include/mmfusion.h"
 
@@ -54,6 +55,28 @@ __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
+}
+
+// ---- tile id of workgroup `orig` in a grouped launch of `total` tiles -----------------------------------
+// The dispatcher deals workgroups to the 8 XCDs round-robin (orig % 8) and in order, so XCD x runs ids x, x+8, ...
+// Tiles are handed out in GRANULES of G consecutive tile ids, granule g to XCD g % 8: the tiles an XCD runs at
+// one time are still neighbours (they share A/B panels in that XCD's L2), and every XCD gets the same mix of
+// problems.  One contiguous range per XCD (G = 0, the first form) is only balanced when all tiles take equally
+// long: with the problems ordered by K descending it gave XCD 0 nothing but the longest tiles and the launch
+// ended when XCD 0 did.  The last (< 8 G) tiles, and launches smaller than that, keep one range per XCD.
+__device__ __forceinline__ int mmf_xcd_tile(int orig, int total, int G) {
+  const int xcd = orig & 7;
+  const int full = G > 0 ? (total / (8 * G)) * (8 * G) : 0;
+  if (orig < full) {
+    const int j = orig >> 3;
+    return ((j / G) * 8 + xcd) * G + (j % G);
+  }
+  const int rest = total - full, q = rest >> 3, r = rest & 7;
+  return full + (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + ((orig - full) >> 3);
+}
+static inline int mmf_xcd_granule() {                       // host: MMF_GEMM_XCD_GRANULE (default 32, 0 = first form)
+  static const int g = [] { const char* e = getenv("MMF_GEMM_XCD_GRANULE"); const int v = e ? atoi(e) : 32; return v > 0 ? v : 0; }();
+  return g;
 }
 
 // ---- counter-based dropout RNG -----------------------------------------------------------------------
