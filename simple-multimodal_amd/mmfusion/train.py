@@ -19,7 +19,7 @@ array, so the whole step (forward, backward, optimiser) can be replayed from one
 from __future__ import annotations
 
 import math
-from typing import Dict, Optional
+from typing import Dict, Iterable, Optional
 
 import torch
 import torch.nn.functional as F
@@ -84,6 +84,91 @@ class FusedAdamW:
     def step(self, lr: Optional[float] = None, grad_scale: float = 1.0) -> None:
         self.set_hparams(lr, grad_scale)
         self.launch()
+
+    # -- checkpoint interchange ------------------------------------------------------------------
+    def state_dict(self, params: Iterable[torch.nn.Parameter]) -> Dict:
+        """The moments in ``torch.optim.AdamW.state_dict()`` layout (what the reference's checkpoints hold,
+        advanced_trainer.py:396-404), one parameter group, parameters numbered in the order of ``params``
+        (pass ``module.parameters()``: the order ``AdamW(module.parameters())`` numbers them in).  Tensors are
+        copies on the CPU."""
+        a = self.arena
+        where = {id(p): i for i, p in enumerate(a.params)}
+        state, ids = {}, []
+        for j, p in enumerate(params):
+            i = where[id(p)]
+            o, n = a.offsets[i], p.numel()
+            ids.append(j)
+            state[j] = {"step": torch.tensor(float(self.t)),
+                        "exp_avg": self.exp_avg[o:o + n].view(p.shape).detach().cpu().clone(),
+                        "exp_avg_sq": self.exp_avg_sq[o:o + n].view(p.shape).detach().cpu().clone()}
+        if len(ids) != len(a.params):
+            raise ValueError("FusedAdamW.state_dict: `params` must enumerate exactly the arena's parameters")
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay,
+                 "amsgrad": False, "maximize": False, "foreach": None, "capturable": False, "differentiable": False,
+                 "fused": None, "decoupled_weight_decay": True, "params": ids}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd: Dict, params: Iterable[torch.nn.Parameter]) -> None:
+        """Inverse of ``state_dict``; also accepts a ``torch.optim.AdamW`` state over the same parameter order
+        with several parameter groups (the reference's two learning-rate groups, advanced_trainer.py:85-94):
+        only the moments and the step count are taken, the hyper-parameters stay this object's."""
+        a = self.arena
+        where = {id(p): i for i, p in enumerate(a.params)}
+        order = [q for g in sd["param_groups"] for q in g["params"]]
+        plist = list(params)
+        if len(order) != len(plist) or len(plist) != len(a.params):
+            raise ValueError(f"FusedAdamW.load_state_dict: checkpoint has {len(order)} parameters, the arena {len(a.params)}")
+        steps = set()
+        with torch.no_grad():
+            self.exp_avg.zero_()
+            self.exp_avg_sq.zero_()
+            for key, p in zip(order, plist):
+                st = sd["state"].get(key)
+                if st is None:                        # a parameter that never received a gradient
+                    continue
+                i = where[id(p)]
+                o, n = a.offsets[i], p.numel()
+                if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                    raise ValueError(f"FusedAdamW.load_state_dict: parameter {key}: moment shape "
+                                     f"{tuple(st['exp_avg'].shape)} vs parameter {tuple(p.shape)}")
+                self.exp_avg[o:o + n].copy_(st["exp_avg"].reshape(-1))
+                self.exp_avg_sq[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
+                steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError(f"FusedAdamW.load_state_dict: parameters at different step counts {sorted(steps)}: "
+                             "the fused kernel applies one bias correction to the whole arena")
+        self.t = steps.pop() if steps else 0
+
+
+def save_checkpoint(path: str, module: torch.nn.Module, optimizer: Optional["FusedAdamW"] = None, *, epoch: int = 0,
+                    metrics: Optional[Dict] = None, config=None, scheduler_state: Optional[Dict] = None) -> None:
+    """Write the reference's checkpoint layout (advanced_trainer.py:396-411): epoch, model_state_dict,
+    optimizer_state_dict, scheduler_state_dict, metrics, config.  ``module.state_dict()`` has the reference's keys
+    and shapes, so the reference's ``load_pretrained_model`` / ``load_state_dict`` read the file as their own."""
+    ckpt = {"epoch": int(epoch),
+            "model_state_dict": {k: v.detach().cpu().clone() for k, v in module.state_dict().items()},
+            "optimizer_state_dict": optimizer.state_dict(module.parameters()) if optimizer is not None else {},
+            "scheduler_state_dict": dict(scheduler_state or {}),
+            "metrics": dict(metrics or {}),
+            "config": config}
+    torch.save(ckpt, path)
+
+
+def load_checkpoint(path: str, module: torch.nn.Module, optimizer: Optional["FusedAdamW"] = None,
+                    arena: Optional[ParamArena] = None) -> Dict:
+    """Restore ``module`` (and the fused optimiser's moments / step count) from a checkpoint in the reference's
+    layout, read with the safe loader (``models.multimodal_model.load_checkpoint_file``).  The parameters live in
+    the arena's fp32 master, which ``load_state_dict`` writes in place; the bf16 shadow is re-cast.  Returns the
+    checkpoint dict (epoch, metrics, scheduler_state_dict, config)."""
+    from models.multimodal_model import load_checkpoint_file
+    ckpt = load_checkpoint_file(path)
+    module.load_state_dict(ckpt["model_state_dict"])
+    if optimizer is not None and ckpt.get("optimizer_state_dict"):
+        optimizer.load_state_dict(ckpt["optimizer_state_dict"], module.parameters())
+    ar = arena if arena is not None else (optimizer.arena if optimizer is not None else None)
+    if ar is not None:
+        ar.refresh(force=True)
+    return ckpt
 
 
 def fusion_loss(outputs: Dict, targets: torch.Tensor, label_smoothing: float = 0.1) -> torch.Tensor:

@@ -149,10 +149,23 @@ def create_model(config, model_type: str = "standard") -> nn.Module:
     raise ValueError(f"Unknown model type: {model_type}")
 
 
+def load_checkpoint_file(checkpoint_path: str) -> Dict:
+    """Read a reference-format checkpoint (advanced_trainer.py:396-411: epoch, model_state_dict,
+    optimizer_state_dict, scheduler_state_dict, metrics, config) without executing anything from the file:
+    ``weights_only=True``, with this package's own ``config`` dataclasses as the only extra classes the unpickler
+    may construct — the reference pickles its ``ExperimentConfig`` instance under the same module path
+    (``config.ExperimentConfig``), which is why a bare ``weights_only=True`` refuses its files.
+    A file that needs any other class is refused with torch's error."""
+    import config as _cfg
+    allow = [getattr(_cfg, n) for n in ("ModelConfig", "DataConfig", "ExperimentConfig") if hasattr(_cfg, n)]
+    with torch.serialization.safe_globals(allow):
+        ckpt = torch.load(checkpoint_path, map_location="cpu", weights_only=True)
+    return ckpt if isinstance(ckpt, dict) and "model_state_dict" in ckpt else {"model_state_dict": ckpt}
+
+
 def load_pretrained_model(checkpoint_path: str, config) -> MultimodalEmotionModel:
-    """Reference-format checkpoints (advanced_trainer.py:396-411): {'model_state_dict': ...} or a bare
-    state_dict.  Loaded with ``weights_only=True`` (nothing in the file is executed)."""
+    """Reference ``load_pretrained_model`` (multimodal_model.py:472-485): {'model_state_dict': ...} or a bare
+    state_dict, loaded through ``load_checkpoint_file`` (nothing in the file is executed)."""
     model = MultimodalEmotionModel(config)
-    ckpt = torch.load(checkpoint_path, map_location="cpu", weights_only=True)
-    model.load_state_dict(ckpt["model_state_dict"] if "model_state_dict" in ckpt else ckpt)
+    model.load_state_dict(load_checkpoint_file(checkpoint_path)["model_state_dict"])
     return model

@@ -268,6 +268,72 @@ def test_fused_adamw_matches_torch():
             assert rel(ops.shadow(p), rp.detach().to(torch.bfloat16), floor=1e-6) < 2 ** -7
 
 
+def test_checkpoint_resume_and_torch_adamw_interchange(tmp_path):
+    """the fused optimiser's state leaves and re-enters in torch.optim.AdamW's state_dict layout
+    inside a reference-layout checkpoint (advanced_trainer.py:396-411).  (1) save after 2 steps, restore into a
+    differently initialised copy, take a third step on both: same parameters and bf16 shadows; (2) the saved
+    optimizer_state_dict loads into a real torch.optim.AdamW over the same parameters, whose third step agrees."""
+    from mmfusion import arena as arena_mod
+    from mmfusion.train import FusedAdamW, load_checkpoint, save_checkpoint
+
+    def make(seed):
+        torch.manual_seed(seed)
+        return torch.nn.Sequential(torch.nn.Linear(40, 72), torch.nn.LayerNorm(72), torch.nn.Linear(72, 8))
+
+    def grads_for(step, params):
+        return [rnd(*p.shape, seed=100 * step + i) * 3 for i, p in enumerate(params)]
+
+    mod = make(0).cuda()
+    ar = arena_mod.ensure(mod)
+    opt = FusedAdamW(ar, lr=1e-2, weight_decay=1e-5, max_grad_norm=1.0)
+    for step in range(2):
+        for p, g in zip(mod.parameters(), grads_for(step, list(mod.parameters()))):
+            p.grad.copy_(g.to(DEV))
+        opt.step()
+    path = str(tmp_path / "ckpt.pth")
+    save_checkpoint(path, mod, opt, epoch=7, metrics={"accuracy": 0.25}, config=None)
+
+    mod2 = make(123).cuda()                                         # different weights until the checkpoint is loaded
+    ar2 = arena_mod.ensure(mod2)
+    opt2 = FusedAdamW(ar2, lr=1e-2, weight_decay=1e-5, max_grad_norm=1.0)
+    ck = load_checkpoint(path, mod2, opt2)
+    assert ck["epoch"] == 7 and ck["metrics"] == {"accuracy": 0.25} and opt2.t == 2
+    for p, q in zip(mod.parameters(), mod2.parameters()):
+        assert torch.equal(p.detach(), q.detach())
+        assert torch.equal(ops.shadow(p), ops.shadow(q))            # the shadow was re-cast from the loaded masters
+
+    ref = make(5)
+    ref.load_state_dict(ck["model_state_dict"])
+    ropt = torch.optim.AdamW(ref.parameters(), lr=1e-2, weight_decay=1e-5)
+    ropt.load_state_dict(ck["optimizer_state_dict"])                # torch validates groups / parameter counts
+
+    g3 = grads_for(2, list(ref.parameters()))
+    for p, q, rp, g in zip(mod.parameters(), mod2.parameters(), ref.parameters(), g3):
+        p.grad.copy_(g.to(DEV))
+        q.grad.copy_(g.to(DEV))
+        rp.grad = g.clone()
+    torch.nn.utils.clip_grad_norm_(ref.parameters(), 1.0)
+    ropt.step()
+    opt.step()
+    opt2.step()
+    for p, q, rp in zip(mod.parameters(), mod2.parameters(), ref.parameters()):
+        assert torch.equal(p.detach(), q.detach())                  # resumed run == uninterrupted run
+        assert rel(q.detach(), rp.detach(), floor=1e-6) < 1e-5      # == torch.optim.AdamW resumed from the same file
+
+    # and the other direction: moments written by torch.optim.AdamW (two parameter groups, as the reference builds them)
+    params = list(ref.parameters())
+    ropt2 = torch.optim.AdamW([{"params": params[:2], "lr": 1e-3}, {"params": params[2:], "lr": 1e-2}], weight_decay=1e-5)
+    for rp, g in zip(params, g3):
+        rp.grad = g.clone()
+    ropt2.step()
+    opt2.load_state_dict(ropt2.state_dict(), mod2.parameters())
+    assert opt2.t == 1
+    sd = opt2.state_dict(mod2.parameters())
+    for j, rp in enumerate(params):
+        assert rel(sd["state"][j]["exp_avg"], ropt2.state[rp]["exp_avg"], floor=1e-9) < 1e-6
+        assert rel(sd["state"][j]["exp_avg_sq"], ropt2.state[rp]["exp_avg_sq"], floor=1e-12) < 1e-6
+
+
 # ---------------------------------------------------------------------------------------- skinny-M linear
 @pytest.mark.parametrize("M,N,K", [(16, 768, 2304), (4, 256, 768), (48, 3072, 768), (64, 384, 768), (1, 8, 8),
                                    (16, 1536, 3840), (3, 72, 40)])

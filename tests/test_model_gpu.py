@@ -122,3 +122,51 @@ def test_meld_shaped_model_matches_oracle(fusion_type):
         assert want is not None, n
         got = params[n].grad.detach().float().cpu()
         assert l2_rel(got, want) <= 0.2, f"{fusion_type}: grad {n} rel L2 {l2_rel(got, want):.3e}"
+
+
+@pytest.mark.parametrize("T,use_adapter", [(499, False), (499, True), (1, False)])
+def test_audio_temporal_head_long_sequence(T, use_adapter):
+    """the audio encoder's temporal head (encoders.py:126-131,151-161) on wav2vec2-length
+    sequences — self-MHA(768, 8 heads, head_dim 96) over T = 499 frames (not a multiple of any tile size: the
+    attention and GEMM kernels' ragged edges), mean over T, Linear(768, d); optionally the AdapterLayer
+    (:271-277) first.  T = 1 is the degenerate sequence (softmax over one key).  Forward and the gradients of
+    the head's parameters and of the input features against the CPU oracle."""
+    import config as cfgmod
+    from models.encoders import AudioEncoder
+    cfg = cfgmod.ModelConfig()
+    cfg.feature_inputs = True
+    cfg.fusion_hidden_size, cfg.fusion_dropout = 512, 0.0
+    torch.manual_seed(11)
+    enc = AudioEncoder(cfg)
+    B = 16 if T > 1 else 4
+    seq = torch.randn(B, T, 768, generator=torch.Generator().manual_seed(99))
+    w = torch.randn(B, 512, generator=torch.Generator().manual_seed(3))
+
+    P = {k: v.detach().float().cpu().clone().requires_grad_(True) for k, v in enc.state_dict().items()}
+    x_ref = seq.clone().requires_grad_(True)
+    h = ref_cpu.adapter_layer(P, "adapter.", x_ref) if use_adapter else x_ref
+    feat_ref, att_ref = ref_cpu.seq_projection_tail(P, "", h, "temporal_attention")
+    ((feat_ref * w).sum() + 1e-3 * att_ref.sum()).backward()
+
+    enc = enc.cuda().eval()          # the AdapterLayer's own Dropout(0.1) (:262) is off, as in the oracle
+    x = seq.cuda().requires_grad_(True)
+    out = enc(x, use_adapter=use_adapter)
+    ((out["features"].float() * w.cuda()).sum() + 1e-3 * out["sequence_output"].float().sum()).backward()
+    torch.cuda.synchronize()
+
+    for name, got, want in (("features", out["features"], feat_ref), ("sequence_output", out["sequence_output"], att_ref)):
+        got, want = got.detach().float().cpu(), want.detach()
+        assert got.shape == want.shape, name
+        err = float((got - want).abs().max())
+        assert err <= OUT_ATOL * max(1.0, float(want.abs().max())), f"T={T}: {name} abs err {err:.3e}"
+    assert l2_rel(x.grad.float().cpu(), x_ref.grad) <= 5e-2, f"T={T}: input grad rel L2 {l2_rel(x.grad.float().cpu(), x_ref.grad):.3e}"
+    names = ["projection.weight", "temporal_attention.in_proj_weight", "temporal_attention.out_proj.weight",
+             "temporal_attention.in_proj_bias"]
+    if use_adapter:
+        names += ["adapter.down_project.weight", "adapter.up_project.weight"]
+    params = dict(enc.named_parameters())
+    for n in names:
+        want = P[n].grad
+        assert want is not None, n
+        got = params[n].grad.detach().float().cpu()
+        assert l2_rel(got, want) <= 5e-2, f"T={T}: grad {n} rel L2 {l2_rel(got, want):.3e}"
