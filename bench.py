@@ -317,6 +317,11 @@ def main():
             fwd_bwd()
             opt_launch()
         if use_graph:                       # two graphs: the all-reduce sits between backward and AdamW
+            # one eager step first: its AdamW launch has written the bf16 shadow (ParamArena.mark_shadow_fresh), so the
+            # forward captured below holds no fp32->bf16 weight cast — every replayed step's shadow comes from the
+            # optimiser kernel of the step before, as in FusionTrainStep (a capture taken before any optimiser launch
+            # recorded the 124 us whole-arena cast into every step although nothing read its result first)
+            eager_step()
             before_replay()
             graph = capture(fwd_bwd)
             graph2 = capture(opt_launch)
