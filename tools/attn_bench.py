@@ -75,7 +75,9 @@ selfp = [("t", "t"), ("a", "a"), ("v", "v")]
 what = sys.argv[1] if len(sys.argv) > 1 else "fwd"
 impls = [int(x) for x in os.environ.get("MMF_ATTN_IMPLS", "1,2,3").split(",")]
 cases = [("cross x6", cross), ("self x3", selfp), ("t<-a only", [("t", "a")]), ("a<-t only", [("a", "t")]),
-         ("t<-t only", [("t", "t")]), ("v<-t only", [("v", "t")]), ("t<-v only", [("t", "v")])]
+         ("t<-t only", [("t", "t")]), ("v<-t only", [("v", "t")]), ("t<-v only", [("t", "v")]),
+         ("big2 t<-a,a<-t", [("t", "a"), ("a", "t")]), ("narrow4 x30", [("t", "v"), ("a", "v"), ("v", "t"), ("v", "a")]),
+         ("grpA t<-a,a<-v,v<-t", [("t", "a"), ("a", "v"), ("v", "t")]), ("grpB t<-v,a<-t,v<-a", [("t", "v"), ("a", "t"), ("v", "a")])]
 if os.environ.get("MMF_ATTN_CASES"):
     want = os.environ["MMF_ATTN_CASES"].split(",")
     cases = [c for c in cases if c[0].split()[0] in want]
@@ -83,7 +85,7 @@ if os.environ.get("MMF_ATTN_B"):
     B = int(os.environ["MMF_ATTN_B"])
 for bwd in ([False] if what == "fwd" else [True] if what == "bwd" else [False, True]):
     for name, pairs in cases:
-        row = f"{'bwd' if bwd else 'fwd'} {name:10s}"
+        row = f"{'bwd' if bwd else 'fwd'} {name:20s}"
         for impl in impls:
             lib.check(lib.load().mmf_attn_select_impl(impl))
             us, tf = run(pairs, bwd)
