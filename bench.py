@@ -303,6 +303,59 @@ def main():
             fn()
         return g
 
+    # N > 1: put the first half of the gradient arena on the wire while the second half of the deferred weight-gradient
+    # launches is still computing.  The step is captured as three graphs sharing one memory pool — forward + backward
+    # with the wgrad problems parked (ops.set_manual_wgrad_flush), then the two halves of the wgrad flush split by
+    # gradient-arena offset — and the all-reduce of a finished arena range is started between the replays
+    # (dp.allreduce_grads_range_async: RCCL's own stream, behind what the compute stream has enqueued so far).
+    # MMF_DP_OVERLAP=0 keeps the one-graph step followed by the whole-arena all-reduce.
+    overlap = world > 1 and use_graph and os.environ.get("MMF_DP_OVERLAP", "1") != "0"
+    compress = None if args.allreduce == "fp32" else "bf16"
+
+    def capture_split(body):
+        """-> (graph of `body` with its wgrad problems parked, [graphs of the wgrad parts], [arena range bounds])"""
+        from mmfusion import ops
+
+        def eager_all():
+            body()
+            parts, _ = ops.split_wgrad_by_offset(ops.take_pending_wgrad(), 2)
+            for part in parts:
+                ops.issue_wgrad(part)
+        ops.set_manual_wgrad_flush(True)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                eager_all()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g1 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g1):
+            body()
+        pend = ops.take_pending_wgrad()                 # operands live in g1's pool; referenced until the parts are captured
+        parts, bounds = ops.split_wgrad_by_offset(pend, 2)
+        gparts = []
+        for part in parts:
+            g = None
+            if part:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=g1.pool()):
+                    ops.issue_wgrad(part)
+            gparts.append(g)
+        del pend, parts
+        ops.set_manual_wgrad_flush(False)
+        return g1, gparts, bounds + [arena.numel]
+
+    def replay_split(g1, gparts, bounds):
+        g1.replay()
+        handles = []
+        for i, g in enumerate(gparts):
+            if g is not None:
+                g.replay()
+            handles.append(dp.allreduce_grads_range_async(arena, bounds[i], bounds[i + 1], compress=compress))
+        for h in handles:
+            h.finish()
+
     if args.workload == "train":
         fwd_bwd, before_replay, exchange, opt_launch = make_train_step(model, xs, arena, world, args.allreduce, rank)
 
@@ -323,11 +376,18 @@ def main():
             # recorded the 124 us whole-arena cast into every step although nothing read its result first)
             eager_step()
             before_replay()
-            graph = capture(fwd_bwd)
+            if overlap:
+                split = capture_split(fwd_bwd)
+            else:
+                graph = capture(fwd_bwd)
             graph2 = capture(opt_launch)
 
         def run_step():
-            if graph is not None:
+            if overlap:
+                before_replay()
+                replay_split(*split)
+                graph2.replay()
+            elif graph is not None:
                 before_replay()
                 graph.replay()
                 exchange()
@@ -337,10 +397,15 @@ def main():
     else:
         eager_step = make_step(args.workload, model, xs, arena)
         profile_step = eager_step
-        if use_graph:
+        if overlap:
+            split = capture_split(eager_step)
+        elif use_graph:
             graph = capture(eager_step)
 
     def run_step_fwdbwd():
+        if overlap:
+            replay_split(*split)
+            return
         if graph is not None:
             graph.replay()
         else:
@@ -368,6 +433,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # optional (MMF_BENCH_CHECKSUM=1): f64 |.|-sum and sum of the gradient arena after the last timed step, to compare
+    # exchange schedules (overlapped vs one-shot all-reduce) on the same inputs
+    checksum = None
+    if os.environ.get("MMF_BENCH_CHECKSUM"):
+        g64 = arena.grads.double()
+        checksum = [float(g64.abs().sum()), float(g64.sum())]
     S = synth.C2_SHAPES
     B = S["B"]
     ms_per_step = elapsed / args.steps * 1e3
@@ -403,7 +474,7 @@ def main():
                                     "train": "hier-seq training step (fwd+bwd+clip+AdamW)"}[args.workload] +
                                    f", B=16/GPU, T_text=512 T_audio=400 T_frames=30 d=768 H=8, fusion_dropout={args.dropout:g}",
                        "global_batch": B * world, "parallelism": f"dp{world}",
-                       "grad_allreduce": (args.allreduce if world > 1 else None),
+                       "grad_allreduce": (args.allreduce if world > 1 else None), "allreduce_overlaps_wgrad": bool(overlap),
                        "graph_replay": bool(use_graph)},
             "step_tflops": round(3 * fwd_flops * B / (ms_per_step * 1e-3) / 1e12, 1) if args.workload == "mult" else None,
             "roofline": roofline,
@@ -426,6 +497,8 @@ def main():
                 "avg_launch_us": round(af["ms_total"] * 1e3 / af["launches"], 2)}
         if world == 1 and not args.no_cpu_baseline and args.workload == "mult":
             line["cpu_baseline"] = cpu_baseline(args.workload)
+        if checksum is not None:
+            line["grad_checksum"] = checksum
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

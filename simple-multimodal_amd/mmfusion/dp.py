@@ -98,6 +98,66 @@ def allreduce_grads(arena, group=None, bucket_bytes: int = DEFAULT_BUCKET_BYTES,
             arena.grads[s:e].mul_(1.0 / world)
 
 
+class _RangePending:
+    """Handle of ``allreduce_grads_range_async``: ``finish()`` waits for the range's buckets and writes the averaged
+    gradients back (widen + 1/world in one kernel for the bf16 wire format)."""
+
+    def __init__(self, arena, items, world, compress):
+        self.arena, self.items, self.world, self.compress = arena, items, world, compress
+
+    def finish(self) -> None:
+        a = self.arena
+        for s, e, work in self.items:
+            work.wait()
+            if self.compress == "bf16":
+                if a.grads.is_cuda:
+                    from . import lib
+                    lib.check(lib.load().mmf_cast_bf16_to_f32_scaled(a._wire_bf16.data_ptr() + 2 * s, a.grads.data_ptr() + 4 * s,
+                                                                     e - s, 1.0 / self.world, lib.stream_ptr()))
+                else:
+                    a.grads[s:e].copy_(a._wire_bf16[s:e])
+                    a.grads[s:e].mul_(1.0 / self.world)
+            else:
+                a.grads[s:e].mul_(1.0 / self.world)
+        self.items = []
+
+
+def allreduce_grads_range_async(arena, start: int, end: int, group=None, bucket_bytes: int = DEFAULT_BUCKET_BYTES,
+                                compress: Optional[str] = None) -> _RangePending:
+    """Start the mean all-reduce of gradient-arena elements [start, end) and return at once: the collective runs on
+    the backend's own stream behind everything enqueued on the current stream so far, so kernels enqueued AFTER this
+    call (the rest of the weight-gradient launches) run beside it.  Used to put the first arena range on the wire
+    while the second half of the deferred wgrad flush is still computing (bench.py, N > 1).  ``finish()`` on the
+    returned handle completes it; ranges must not overlap and nothing may write [start, end) until then."""
+    if compress not in (None, "bf16"):
+        raise ValueError("compress must be None or 'bf16'")
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1 or end <= start:
+        return _RangePending(arena, [], world, compress)
+    items = []
+    if compress == "bf16":
+        wire = getattr(arena, "_wire_bf16", None)
+        if wire is None or wire.numel() != arena.grads.numel():
+            wire = torch.empty(arena.grads.numel(), dtype=torch.bfloat16, device=arena.grads.device)
+            arena._wire_bf16 = wire
+        gpu = arena.grads.is_cuda
+        if gpu:
+            from . import lib
+            L = lib.load()
+        for s, e in bucket_bounds(end - start, 2, bucket_bytes):
+            s, e = s + start, e + start
+            if gpu:
+                lib.check(L.mmf_cast_f32_to_bf16(arena.grads.data_ptr() + 4 * s, wire.data_ptr() + 2 * s, e - s, lib.stream_ptr()))
+            else:
+                wire[s:e].copy_(arena.grads[s:e])
+            items.append((s, e, dist.all_reduce(wire[s:e], op=dist.ReduceOp.SUM, group=group, async_op=True)))
+    else:
+        for s, e in bucket_bounds(end - start, 4, bucket_bytes):
+            s, e = s + start, e + start
+            items.append((s, e, dist.all_reduce(arena.grads[s:e], op=dist.ReduceOp.SUM, group=group, async_op=True)))
+    return _RangePending(arena, items, world, compress)
+
+
 def broadcast_params(arena, src: int = 0, group=None) -> None:
     """Make the replicas identical (rank ``src``'s masters win), then refresh the bf16 shadow."""
     if dist.is_initialized() and dist.get_world_size(group) > 1:

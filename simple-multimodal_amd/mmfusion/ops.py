@@ -284,6 +284,63 @@ def _issue_wgrad_side(pend: List[tuple]) -> None:
         q[1].record_stream(_wgrad_stream)
 
 
+# Manual flush (data-parallel overlap, bench.py / mmfusion.dp): the end-of-backward callback only parks the queued
+# problems; the caller takes them (take_pending_wgrad), splits them by gradient-arena offset (split_wgrad_by_offset)
+# and issues the parts itself (issue_wgrad) with the all-reduce of a finished arena range started in between.
+_MANUAL_FLUSH = False
+_parked_wgrad: List[tuple] = []
+
+
+def set_manual_wgrad_flush(on: bool) -> None:
+    global _MANUAL_FLUSH
+    if not DEFER_WGRAD and on:
+        raise RuntimeError("manual wgrad flush needs the deferred wgrad queue (MMF_DEFER_WGRAD=1)")
+    _MANUAL_FLUSH = bool(on)
+
+
+def take_pending_wgrad() -> List[tuple]:
+    """The problems the last backward parked (manual flush mode), in queue order; the list is handed over."""
+    global _parked_wgrad
+    pend, _parked_wgrad = _parked_wgrad, []
+    return pend
+
+
+def wgrad_offset(q: tuple) -> int:
+    """Element offset of a queued problem's weight gradient inside its gradient arena."""
+    from .arena import arena_of
+    ar = arena_of(q[2])
+    if ar is None:
+        raise ValueError("queued weight gradient does not live in a gradient arena")
+    return (q[2].data_ptr() - ar.grads.data_ptr()) // 4
+
+
+def split_wgrad_by_offset(pend: List[tuple], nparts: int = 2) -> Tuple[List[List[tuple]], List[int]]:
+    """Partition queued problems into `nparts` consecutive gradient-arena ranges of about equal GEMM work
+    (sum of M N K).  Returns (parts, bounds): part i holds every problem whose gradient starts in
+    [bounds[i], bounds[i+1]); bounds[0] = 0 and the last bound is open (the caller's arena size).  Problems that write
+    the same region fall in the same part, so the overwrite-then-accumulate order inside a part is kept."""
+    items = sorted(((wgrad_offset(q), i, q) for i, q in enumerate(pend)), key=lambda t: (t[0], t[1]))
+    work = [q[2].shape[0] * q[2].shape[1] * q[0].shape[0] for _, _, q in items]
+    total, acc, cuts = float(sum(work)) or 1.0, 0.0, []
+    for k in range(len(items)):
+        if len(cuts) < nparts - 1 and k > 0 and items[k][0] != items[k - 1][0] and acc >= total * (len(cuts) + 1) / nparts:
+            cuts.append(k)
+        acc += work[k]
+    edges = [0] + cuts + [len(items)]
+    parts = [[q for _, _, q in items[edges[i]:edges[i + 1]]] for i in range(len(edges) - 1)]
+    bounds = [0] + [items[c][0] for c in cuts]
+    while len(parts) < nparts:                            # fewer distinct regions than parts: empty trailing parts
+        parts.append([])
+        bounds.append(bounds[-1] if not items else items[-1][0] + items[-1][2][2].numel())
+    return parts, bounds
+
+
+def issue_wgrad(pend: List[tuple]) -> None:
+    """Issue queued wgrad problems now, on the current stream (grouped launches, as the automatic flush does)."""
+    if pend:
+        _issue_wgrad(pend)
+
+
 def _flush_wgrad() -> None:
     global _pending_wgrad, _callback_queued, _pending_tiles
     pend, _pending_wgrad = _pending_wgrad, []
@@ -294,6 +351,9 @@ def _flush_wgrad() -> None:
         for q in pend:
             q[0].record_stream(cur)
             q[1].record_stream(cur)
+    if _MANUAL_FLUSH:
+        _parked_wgrad.extend(pend)
+        return
     if _WGRAD_SIDE:
         if pend:
             _issue_wgrad_side(pend)

@@ -48,7 +48,20 @@ def _worker(rank, world, port, q):
     fake = SimpleNamespace(grads=shard.clone())
     dp.allreduce_grads(fake, compress="bf16", bucket_bytes=100_000)
     cerr = float((fake.grads - full / world).abs().max() / (full / world).abs().max())
-    q.put((rank, err, float(avg.min()), float(avg.max()), cerr))
+    # range-wise asynchronous form (what bench.py overlaps with the second half of the wgrad flush): two ranges
+    # started one after the other, finished in order, must give the same result as the one-shot call, both formats
+    n, cut = shard.numel(), (shard.numel() // 3) // 64 * 64
+    rerr = []
+    for compress in (None, "bf16"):
+        one = SimpleNamespace(grads=shard.clone())
+        dp.allreduce_grads(one, compress=compress, bucket_bytes=100_000)
+        two = SimpleNamespace(grads=shard.clone())
+        hA = dp.allreduce_grads_range_async(two, 0, cut, compress=compress, bucket_bytes=100_000)
+        hB = dp.allreduce_grads_range_async(two, cut, n, compress=compress, bucket_bytes=100_000)
+        hA.finish()
+        hB.finish()
+        rerr.append(float((two.grads - one.grads).abs().max()))
+    q.put((rank, err, float(avg.min()), float(avg.max()), cerr, max(rerr)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -64,10 +77,11 @@ def test_two_rank_gradient_allreduce_matches_full_batch():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, err, lo, hi, cerr in res:
+    for rank, err, lo, hi, cerr, rerr in res:
         assert err < 1e-5, f"rank {rank}: all-reduced gradient deviates by {err}"
         assert lo == hi == 1.5
         assert cerr < 2 ** -6, f"rank {rank}: bf16-compressed all-reduce deviates by {cerr}"
+        assert rerr == 0.0, f"rank {rank}: range-wise all-reduce differs from the one-shot call by {rerr}"
 
 
 def test_bucket_bounds_cover_exactly():
