@@ -455,7 +455,8 @@ def main():
         dom = max(prof, key=lambda k: prof[k]["ms_total"])
         dsec = prof[dom]["ms_total"] * 1e-3
         ach = prof[dom]["flops_total"] / dsec / 1e12
-        traffic, mfma_util = pmc_lookup(dom)
+        # the committed PMC passes are of the MulT workload: its per-launch byte counts do not describe the other workloads' launches
+        traffic, mfma_util = pmc_lookup(dom) if args.workload == "mult" else (None, None)
         roofline = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": BF16_MFMA_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                     "mfma_util_pmc": mfma_util,
