@@ -416,6 +416,9 @@ def main():
     if args.workload != "train":
         run_step = run_step_fwdbwd
 
+    if world > 1:                       # communicator set-up and the first collective's lazy work stay out of the timed region
+        dist.all_reduce(torch.zeros(64, device=device))
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         run_step()
     if world > 1:
