@@ -253,6 +253,8 @@ int mmf_dropout(const void* x, void* y, int64_t n, int is_f32, float p, const ui
 int mmf_zero_ranges_f32(float* base, const int64_t* starts, const int64_t* ends, int n, void* stream);
 /* relu backward on bf16: dx = dy * (y > 0) */
 int mmf_relu_bwd_bf16(const void* dy, const void* y, void* dx, int64_t n, void* stream);
+/* same with dy and / or y in f32 (flags non-zero): narrows and masks in one pass; dx is bf16 */
+int mmf_relu_bwd_mixed(const void* dy, int dy_f32, const void* y, int y_f32, void* dx, int64_t n, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Small fused kernels of the (B, d)-row branches (csrc/small.hip).  f32 unless said otherwise; every buffer

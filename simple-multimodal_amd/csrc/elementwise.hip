@@ -383,6 +383,35 @@ extern "C" int mmf_dropout(const void* x, void* y, int64_t n, int is_f32, float 
   return MMF_OK;
 }
 
+// dx (bf16) = dy * (y > 0) with dy and / or y in f32: the gradient of an f32-output linear with ReLU narrowed and
+// masked in one pass (was: cast dy, cast y, mask = three launches of a (B, d)-row chain where a launch is ~5 us)
+template <bool DY_F32, bool Y_F32>
+__global__ __launch_bounds__(EW_THREADS)
+void relu_bwd_mixed_kernel(const void* __restrict__ dy_, const void* __restrict__ y_, unsigned short* __restrict__ dx, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * EW_THREADS;
+  for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n; i += stride) {
+    const float g = DY_F32 ? static_cast<const float*>(dy_)[i]
+                           : __uint_as_float((unsigned)static_cast<const unsigned short*>(dy_)[i] << 16);
+    const float v = Y_F32 ? static_cast<const float*>(y_)[i]
+                          : __uint_as_float((unsigned)static_cast<const unsigned short*>(y_)[i] << 16);
+    dx[i] = v > 0.f ? f32_to_bf16_bits(g) : (unsigned short)0;
+  }
+}
+
+extern "C" int mmf_relu_bwd_mixed(const void* dy, int dy_f32, const void* y, int y_f32, void* dx, int64_t n, void* stream) {
+  if (n <= 0) return MMF_OK;
+  if (!dy || !y || !dx) MMF_FAIL(MMF_E_SHAPE, "mmf_relu_bwd_mixed: null pointer");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  unsigned short* o = static_cast<unsigned short*>(dx);
+  const dim3 grid(ew_grid(n)), block(EW_THREADS);
+  if (dy_f32 && y_f32)       hipLaunchKernelGGL((relu_bwd_mixed_kernel<true, true>), grid, block, 0, s, dy, y, o, n);
+  else if (dy_f32)           hipLaunchKernelGGL((relu_bwd_mixed_kernel<true, false>), grid, block, 0, s, dy, y, o, n);
+  else if (y_f32)            hipLaunchKernelGGL((relu_bwd_mixed_kernel<false, true>), grid, block, 0, s, dy, y, o, n);
+  else                       hipLaunchKernelGGL((relu_bwd_mixed_kernel<false, false>), grid, block, 0, s, dy, y, o, n);
+  MMF_CHECK_LAUNCH("mmf_relu_bwd_mixed");
+  return MMF_OK;
+}
+
 extern "C" int mmf_relu_bwd_bf16(const void* dy, const void* y, void* dx, int64_t n, void* stream) {
   if (n <= 0) return MMF_OK;
   if (!dy || !y || !dx) MMF_FAIL(MMF_E_SHAPE, "mmf_relu_bwd_bf16: null pointer");

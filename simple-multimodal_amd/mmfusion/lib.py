@@ -25,7 +25,7 @@ SYMBOLS = (
     "mmf_attn_fwd_grouped_ex", "mmf_attn_bwd_grouped_ex", "mmf_dropout", "mmf_attn_select_impl",
     "mmf_attn_fwd_grouped", "mmf_attn_bwd_grouped", "mmf_layernorm_fwd_grouped",
     "mmf_layernorm_bwd_grouped", "mmf_layernorm_bwd_workspace_bytes", "mmf_cast_f32_to_bf16", "mmf_cast_bf16_to_f32", "mmf_cast_bf16_to_f32_scaled", "mmf_cast_f32_to_bf16_2d", "mmf_add3_bf16",
-    "mmf_meanpool_fwd", "mmf_meanpool_bwd", "mmf_meanpool_cat_fwd", "mmf_meanpool_cat_bwd", "mmf_colsum_bf16", "mmf_colsum_grouped", "mmf_relu_bwd_bf16",
+    "mmf_meanpool_fwd", "mmf_meanpool_bwd", "mmf_meanpool_cat_fwd", "mmf_meanpool_cat_bwd", "mmf_colsum_bf16", "mmf_colsum_grouped", "mmf_relu_bwd_bf16", "mmf_relu_bwd_mixed",
     "mmf_sqnorm_f32", "mmf_adamw_step", "mmf_skinny_linear_fwd", "mmf_skinny_linear_dgrad",
     "mmf_gat3_dense_fwd", "mmf_gat3_dense_bwd", "mmf_infonce_fwd", "mmf_infonce_bwd", "mmf_adaptive_combine_fwd",
     "mmf_adaptive_combine_bwd", "mmf_adaptive_attn_weights", "mmf_linear_narrow_fwd", "mmf_linear_narrow_bwd", "mmf_stack3_embed_fwd",
@@ -120,6 +120,7 @@ def load() -> C.CDLL:
     lib.mmf_colsum_bf16.argtypes = [vp, vp, i32, i32, i32, vp]
     lib.mmf_colsum_grouped.argtypes = [C.POINTER(ColsumProblem), i32, vp]
     lib.mmf_relu_bwd_bf16.argtypes = [vp, vp, vp, i64, vp]
+    lib.mmf_relu_bwd_mixed.argtypes = [vp, C.c_int, vp, C.c_int, vp, i64, vp]
     lib.mmf_skinny_linear_fwd.argtypes = [C.POINTER(SkinnyProblem), i32, i32, i32, vp]
     lib.mmf_skinny_linear_dgrad.argtypes = [C.POINTER(SkinnyProblem), i32, i32, f32, i32, vp]
     lib.mmf_sqnorm_f32.argtypes = [vp, i64, vp, vp]

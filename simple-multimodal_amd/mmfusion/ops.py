@@ -432,6 +432,25 @@ class LinearSpec:
     has_residual: bool = False
 
 
+def _relu_mask(g: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    """dz (bf16) = g * (y > 0) for a ReLU output y; g and y may be f32 (an f32-output linear) — narrowed and masked
+    by ONE kernel instead of cast, cast, mask (these are (B, d)-row tensors: a launch costs more than the work)."""
+    g, y = g.contiguous(), y.contiguous()
+    if g.shape != y.shape:
+        raise ValueError("relu mask: gradient and saved output differ in shape")
+    dz = torch.empty(g.shape, dtype=BF16, device=g.device)
+    L, st = lib.load(), lib.stream_ptr()
+    if g.dtype == BF16 and y.dtype == BF16:
+        lib.check(L.mmf_relu_bwd_bf16(g.data_ptr(), y.data_ptr(), dz.data_ptr(), g.numel(), st))
+    else:
+        for t in (g, y):
+            if t.dtype not in (BF16, torch.float32):
+                raise TypeError("relu mask: bf16 or f32 tensors only")
+        lib.check(L.mmf_relu_bwd_mixed(g.data_ptr(), int(g.dtype == torch.float32), y.data_ptr(),
+                                       int(y.dtype == torch.float32), dz.data_ptr(), g.numel(), st))
+    return dz
+
+
 class _GroupedLinear(torch.autograd.Function):
     """tensors = [x_0, res_0|None, w_0.p, b_0.p|None, x_1, ...]; returns one output per spec."""
 
@@ -457,8 +476,14 @@ class _GroupedLinear(torch.autograd.Function):
                 raise ValueError("a concatenated linear group needs equal row counts")
             base = torch.empty((M0, sum(s.w.w16.shape[0] for s in specs)), dtype=torch.float32 if out_f32 else BF16,
                                device=tensors[0].device)
+        f32_in = []
         for i, s in enumerate(specs):
             x, res = tensors[4 * i], tensors[4 * i + 1]
+            # an f32 input (a module's f32 output fed on, e.g. MulT's pooled projections) is narrowed here and its
+            # gradient written as f32 by the dgrad kernel: no bf16 -> f32 cast node in the backward chain
+            f32_in.append(x.dtype == torch.float32)
+            if f32_in[-1]:
+                x = cast_to_bf16(x.contiguous())
             _req(x, BF16)
             w16 = s.w.w16
             bias = s.b.master if has_bias else None
@@ -478,6 +503,9 @@ class _GroupedLinear(torch.autograd.Function):
                             for (x, w, y, b, _) in probs], epi, out_f32)
         else:
             gemm_group(GEMM_NT, probs, epi)
+        if any(f32_in) and not all(f32_in):
+            raise ValueError("a linear group's inputs must share one dtype")
+        ctx.f32_in = bool(f32_in and f32_in[0])
         ctx.specs, ctx.out_f32, ctx.cat = specs, out_f32, cat
         ctx.save_for_backward(*xs, *(([base] if cat else outs) if relu else []))
         ctx.x_needs = [tensors[4 * i].requires_grad for i in range(n)]
@@ -496,14 +524,12 @@ class _GroupedLinear(torch.autograd.Function):
         if ctx.cat:                                # one gradient for the concatenated output: slice it, no copies
             g = gys[0]
             if g is not None:
-                g = g.contiguous()
-                if g.dtype != BF16:
-                    g = cast_to_bf16(g)
                 if specs[0].relu:
-                    y = ys[0] if ys[0].dtype == BF16 else cast_to_bf16(ys[0])
-                    dz = torch.empty_like(g)
-                    lib.check(L.mmf_relu_bwd_bf16(g.data_ptr(), y.data_ptr(), dz.data_ptr(), g.numel(), st))
-                    g = dz
+                    g = _relu_mask(g, ys[0])
+                else:
+                    g = g.contiguous()
+                    if g.dtype != BF16:
+                        g = cast_to_bf16(g)
             off = 0
             for s in specs:
                 nout = s.w.w16.shape[0]
@@ -515,12 +541,10 @@ class _GroupedLinear(torch.autograd.Function):
             if g is None:
                 dys.append(None)
                 continue
-            g = cast_to_bf16(g) if g.dtype != BF16 else g.contiguous()      # (the cast takes row-strided sources)
             if specs[0].relu:                      # dz = dy * (y > 0)
-                y = ys[i] if ys[i].dtype == BF16 else cast_to_bf16(ys[i])
-                dz = torch.empty_like(g)
-                lib.check(L.mmf_relu_bwd_bf16(g.data_ptr(), y.data_ptr(), dz.data_ptr(), g.numel(), st))
-                g = dz
+                g = _relu_mask(g, ys[i])
+            else:
+                g = cast_to_bf16(g) if g.dtype != BF16 else g.contiguous()      # (the cast takes row-strided sources)
             dys.append(g)
         dgrad = []
         has_bias = specs[0].b is not None
@@ -530,7 +554,7 @@ class _GroupedLinear(torch.autograd.Function):
             if g is None:
                 continue
             if ctx.x_needs[i]:
-                dx = torch.empty(xs[i].shape, dtype=BF16, device=g.device)
+                dx = torch.empty(xs[i].shape, dtype=torch.float32 if ctx.f32_in else BF16, device=g.device)
                 dgrad.append((g, s.w.w16, dx, None, None))
                 grads[4 * i] = dx
             # wgrad; the bias gradient (column sums of dy) rides along in the same kernel
@@ -541,7 +565,7 @@ class _GroupedLinear(torch.autograd.Function):
             if _SKINNY and all(g.shape[0] <= lib.SKINNY_MAX_M for (g, _, _, _, _) in dgrad):
                 lib.skinny_dgrad([lib.SkinnyProblem(g.data_ptr(), w.data_ptr(), dx.data_ptr(), None, None,
                                                     g.shape[0], w.shape[0], w.shape[1], _ld(g), _ld(w), _ld(dx), 0)
-                                  for (g, w, dx, _, _) in dgrad], 0, 1.0, False)
+                                  for (g, w, dx, _, _) in dgrad], 0, 1.0, ctx.f32_in)
             else:
                 gemm_group(GEMM_NN, dgrad, 0)
         return (None, None, *grads)

@@ -319,7 +319,7 @@ class MultimodalTransformer(_FusionBase):
         pooled_att = ops.meanpool_cat([att[0].view(B, Tt, d), att[1].view(B, Ta, d), att[2].view(B, Tv, d)])
         pf = ops.linear_group([(x, _lin(m.out_proj), None) for x, m in zip(sops.split3(pooled_att), mhas)],
                               out_f32=True, cat=True)                           # :171 (B, 3d) f32, written in place
-        fused = ops.dropout(ops.linear(ops.to_bf16(pf), *_wb(self.final_fusion[0]), relu=True, out_f32=True),
+        fused = ops.dropout(ops.linear(pf, *_wb(self.final_fusion[0]), relu=True, out_f32=True),
                             p, True)                                            # :172
         return {"fused_features": fused, "text_features": pf[:, :d], "audio_features": pf[:, d:2 * d],
                 "video_features": pf[:, 2 * d:]}
