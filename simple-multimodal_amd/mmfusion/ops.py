@@ -549,12 +549,30 @@ class _GroupedLinear(torch.autograd.Function):
         dgrad = []
         has_bias = specs[0].b is not None
         grads: List[Optional[torch.Tensor]] = [None] * (4 * n)
+        # inputs that are the adjacent column blocks of one contiguous tensor (small_ops.split3 of a pooled (B, 3d)
+        # buffer) get their gradients as the same blocks of one buffer, so the split's backward has nothing to copy
+        dbase, col = None, 0
+        x0 = xs[0]
+        if (n > 1 and not ctx.f32_in and all(ctx.x_needs) and all(g is not None for g in dys) and x0._base is not None
+                and x0._base.is_contiguous() and x0._base.dim() == 2 and x0.data_ptr() == x0._base.data_ptr()
+                and x0._base.shape[1] == sum(x.shape[1] for x in xs) and x0._base.shape[0] == x0.shape[0]):
+            off, ok = 0, True
+            for x in xs:
+                ok = ok and x._base is x0._base and x.stride(0) == x0._base.shape[1] and \
+                    x.data_ptr() == x0._base.data_ptr() + 2 * off and x.shape[0] == x0.shape[0]
+                off += x.shape[1]
+            if ok:
+                dbase = torch.empty(x0._base.shape, dtype=BF16, device=x0.device)
         for i, s in enumerate(specs):
             g = dys[i]
             if g is None:
                 continue
             if ctx.x_needs[i]:
-                dx = torch.empty(xs[i].shape, dtype=torch.float32 if ctx.f32_in else BF16, device=g.device)
+                if dbase is not None:
+                    dx = dbase[:, col:col + xs[i].shape[1]]
+                    col += xs[i].shape[1]
+                else:
+                    dx = torch.empty(xs[i].shape, dtype=torch.float32 if ctx.f32_in else BF16, device=g.device)
                 dgrad.append((g, s.w.w16, dx, None, None))
                 grads[4 * i] = dx
             # wgrad; the bias gradient (column sums of dy) rides along in the same kernel

@@ -150,6 +150,37 @@ def test_gemm_grouped_many_tiles_mixed_k(layout, impl):
         assert rel(C, ref) < 1e-5, f"problem {i}: {rel(C, ref):.3e}"
 
 
+def test_linear_group_on_split3_returns_one_gradient_buffer():
+    """Three linears on the column thirds of one pooled (B, 3d) tensor (MulT's pooled out-projections, :171): the input
+    gradients come back as the thirds of one buffer and split3's backward returns that buffer (no concatenation
+    kernel); an f32-output ReLU linear fed with an f32 tensor (final_fusion, :172) masks and narrows its gradient in one
+    kernel and writes an f32 input gradient.  Checked against torch autograd on the same bf16-rounded operands."""
+    from mmfusion import arena as arena_mod, small_ops as sops
+    B, d = 16, 64
+    torch.manual_seed(3)
+    lins = torch.nn.ModuleList([torch.nn.Linear(d, d) for _ in range(3)] + [torch.nn.Linear(3 * d, d)]).cuda()
+    arena_mod.ensure(lins)
+    c = bf(rnd(B, 3 * d, seed=21)).requires_grad_(True)
+    wsum = rnd(B, d, seed=22).to(DEV)
+    hits0 = sops.split3_nocopy_hits
+    pf = ops.linear_group([(x, ops.LinearSpec(ops.W(l.weight), ops.W(l.bias), False), None)
+                           for x, l in zip(sops.split3(c), lins[:3])], out_f32=True, cat=True)
+    y = ops.linear(pf, ops.W(lins[3].weight), ops.W(lins[3].bias), relu=True, out_f32=True)
+    assert pf.dtype == torch.float32 and y.dtype == torch.float32
+    (y * wsum).sum().backward()
+    torch.cuda.synchronize()
+    assert sops.split3_nocopy_hits == hits0 + 1, "split3 backward concatenated although its gradients were one buffer"
+    # reference: same bf16-rounded weights / inputs, f32 math
+    cr = c.detach().float().cpu().requires_grad_(True)
+    ws = [l.weight.detach().to(torch.bfloat16).float().cpu() for l in lins]
+    bs = [l.bias.detach().float().cpu() for l in lins]
+    pr = torch.cat([cr[:, i * d:(i + 1) * d] @ ws[i].t() + bs[i] for i in range(3)], dim=1)
+    yr = torch.relu(pr.to(torch.bfloat16).float() @ ws[3].t() + bs[3])
+    (yr * wsum.cpu()).sum().backward()
+    assert rel(y, yr) < 2e-2 and rel(pf, pr) < 1e-2
+    assert rel(c.grad, cr.grad) < 3e-2
+
+
 def test_gemm_rejects_bad_shapes():
     a, b = bf(rnd(16, 12)), bf(rnd(8, 12))
     with pytest.raises(RuntimeError, match="granularity"):
