@@ -221,6 +221,14 @@ int mmf_cast_f32_to_bf16_2d(const float* src, void* dst, int rows, int cols, int
 int mmf_cast_bf16_to_f32_scaled(const void* src, float* dst, int64_t n, float scale, void* stream);
 /* y = a + b + c (bf16); models/fusion_layers.py:156-158.  c may be NULL (y = a + b). */
 int mmf_add3_bf16(const void* a, const void* b, const void* c, void* y, int64_t n, void* stream);
+/* several three-operand sums in one launch (y_i = a_i + b_i + c_i, bf16, n_i elements each) */
+#define MMF_ADD3_MAX 8
+typedef struct mmf_add3_problem {
+  const void* a; const void* b; const void* c;
+  void* y;
+  int64_t n;
+} mmf_add3_problem;
+int mmf_add3_grouped(const mmf_add3_problem* problems, int num_problems, void* stream);
 /* y[b][j] = mean_t x[b][t][j]  (models/fusion_layers.py:166-168); x bf16 [B][T][d], y bf16 with
  * row stride ldy (lets the three pooled modalities land side by side = torch.cat, :171). */
 int mmf_meanpool_fwd(const void* x, void* y, int B, int T, int d, int ldy, void* stream);

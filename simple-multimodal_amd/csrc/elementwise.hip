@@ -103,6 +103,40 @@ void add3_kernel(const unsigned short* __restrict__ a, const unsigned short* __r
   }
 }
 
+// grouped form: up to MMF_ADD3_MAX problems in one launch (MulT's three residual sums x_m + two cross outputs,
+// reference :156-158, sit in the single-stream part of the step where every launch is exposed)
+struct Add3Args {
+  int n;
+  int blk_start[MMF_ADD3_MAX + 1];
+  mmf_add3_problem p[MMF_ADD3_MAX];
+};
+__global__ __launch_bounds__(EW_THREADS)
+void add3_grouped_kernel(const Add3Args a) {
+  int pi = 0;
+  while (pi + 1 < a.n && (int)blockIdx.x >= a.blk_start[pi + 1]) ++pi;
+  const mmf_add3_problem& P = a.p[pi];
+  const unsigned short* __restrict__ x = static_cast<const unsigned short*>(P.a);
+  const unsigned short* __restrict__ y = static_cast<const unsigned short*>(P.b);
+  const unsigned short* __restrict__ z = static_cast<const unsigned short*>(P.c);
+  unsigned short* __restrict__ o = static_cast<unsigned short*>(P.y);
+  const int64_t nvec = P.n >> 3;
+  const int nblk = a.blk_start[pi + 1] - a.blk_start[pi], blk = (int)blockIdx.x - a.blk_start[pi];
+  const int64_t stride = (int64_t)nblk * EW_THREADS;
+  for (int64_t i = (int64_t)blk * EW_THREADS + threadIdx.x; i < nvec; i += stride) {
+    const u32x4_t va = *reinterpret_cast<const u32x4_t*>(x + i * 8);
+    const u32x4_t vb = *reinterpret_cast<const u32x4_t*>(y + i * 8);
+    const u32x4_t vc = *reinterpret_cast<const u32x4_t*>(z + i * 8);
+    u32x4_t r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = add3_pk(va[e], vb[e], vc[e]);
+    *reinterpret_cast<u32x4_t*>(o + i * 8) = r;
+  }
+  if (blk == 0) {
+    const int64_t t = (nvec << 3) + threadIdx.x;
+    if (t < P.n) o[t] = f32_to_bf16_bits(bf16_bits_to_f32(x[t]) + bf16_bits_to_f32(y[t]) + bf16_bits_to_f32(z[t]));
+  }
+}
+
 __global__ __launch_bounds__(EW_THREADS)
 void relu_bwd_kernel(const unsigned short* __restrict__ dy, const unsigned short* __restrict__ y,
                      unsigned short* __restrict__ dx, int64_t n) {
@@ -364,6 +398,27 @@ extern "C" int mmf_add3_bf16(const void* a, const void* b, const void* c, void* 
                      static_cast<const unsigned short*>(a), static_cast<const unsigned short*>(b),
                      static_cast<const unsigned short*>(c), static_cast<unsigned short*>(y), n);
   MMF_CHECK_LAUNCH("mmf_add3_bf16");
+  return MMF_OK;
+}
+
+extern "C" int mmf_add3_grouped(const mmf_add3_problem* problems, int num_problems, void* stream) {
+  if (!problems || num_problems <= 0 || num_problems > MMF_ADD3_MAX)
+    MMF_FAIL(MMF_E_SHAPE, "mmf_add3_grouped: num_problems=%d not in 1..%d", num_problems, MMF_ADD3_MAX);
+  Add3Args a;
+  a.n = num_problems;
+  int total = 0;
+  for (int i = 0; i < num_problems; ++i) {
+    const mmf_add3_problem& q = problems[i];
+    if (q.n <= 0) MMF_FAIL(MMF_E_SHAPE, "mmf_add3_grouped[%d]: n=%lld", i, (long long)q.n);
+    EW_PTR_CHECK("mmf_add3_grouped", q.a && q.b && q.c && q.y && mmf_aligned16(q.a) && mmf_aligned16(q.b) &&
+                 mmf_aligned16(q.c) && mmf_aligned16(q.y));
+    a.blk_start[i] = total;
+    total += ew_grid(q.n >> 3);
+    a.p[i] = q;
+  }
+  a.blk_start[num_problems] = total;
+  hipLaunchKernelGGL(add3_grouped_kernel, dim3(total), dim3(EW_THREADS), 0, static_cast<hipStream_t>(stream), a);
+  MMF_CHECK_LAUNCH("mmf_add3_grouped");
   return MMF_OK;
 }
 

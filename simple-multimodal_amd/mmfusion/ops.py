@@ -858,6 +858,41 @@ def add3(a, b, c=None):
     return _Add3.apply(a, b, c)
 
 
+class _Add3Group(torch.autograd.Function):
+    """tensors = [a_0, b_0, c_0, a_1, ...] (bf16): y_i = a_i + b_i + c_i for all i in ONE launch."""
+
+    @staticmethod
+    def forward(ctx, *tensors):
+        n = len(tensors) // 3
+        probs, outs, keep = [], [], []
+        for i in range(n):
+            a, b, c = (t.contiguous() for t in tensors[3 * i:3 * i + 3])
+            _req(a, BF16), _req(b, BF16), _req(c, BF16)
+            if a.shape != b.shape or a.shape != c.shape:
+                raise ValueError("add3 group: operands of one sum must have one shape")
+            y = torch.empty_like(a)
+            keep += [a, b, c]
+            outs.append(y)
+            probs.append(lib.Add3Problem(a.data_ptr(), b.data_ptr(), c.data_ptr(), y.data_ptr(), a.numel()))
+        arr = (lib.Add3Problem * n)(*probs)
+        lib.check(lib.load().mmf_add3_grouped(arr, n, lib.stream_ptr()))
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        out = []
+        for g in gs:
+            out += [g, g, g]
+        return tuple(out)
+
+
+def add3_group(triples: Sequence[tuple]) -> List[torch.Tensor]:
+    """[(a, b, c), ...] -> [a + b + c, ...], one launch (up to lib.ADD3_MAX sums)."""
+    if not 0 < len(triples) <= lib.ADD3_MAX:
+        raise ValueError(f"add3 group of {len(triples)} sums (1..{lib.ADD3_MAX})")
+    return list(_Add3Group.apply(*[t for tr in triples for t in tr]))
+
+
 class _MeanPoolCat(torch.autograd.Function):
     """xs: (B, T_i, d) bf16 -> (B, n*d) bf16 = cat_i mean_t x_i  (fusion_layers.py:166-171)."""
 

@@ -309,7 +309,7 @@ class MultimodalTransformer(_FusionBase):
             t_a, t_v, a_t, a_v, v_t, v_a = outs
         else:
             t_a, t_v, a_t, a_v, v_t, v_a = _cross_blocks(blocks, qs, kvs, B, Tqs, Tks, p)    # :146-153
-        et, ea, ev = ops.add3(t, t_a, t_v), ops.add3(a, a_t, a_v), ops.add3(v, v_t, v_a)   # :156-158
+        et, ea, ev = ops.add3_group([(t, t_a, t_v), (a, a_t, a_v), (v, v_t, v_a)])         # :156-158, one launch
         # :161-168.  The self-attention outputs are only ever used through their mean over T, and the
         # out-projection is affine, so mean_t(out_proj(o_t)) == out_proj(mean_t o_t): pool the attention
         # output first and run the three out-projections on (B, d) instead of (B*T, d) rows — the same

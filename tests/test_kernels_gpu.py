@@ -181,6 +181,21 @@ def test_linear_group_on_split3_returns_one_gradient_buffer():
     assert rel(c.grad, cr.grad) < 3e-2
 
 
+def test_add3_group_matches_three_sums():
+    """MulT's three residual sums (:156-158) as one launch; ragged element counts (one not a multiple of 8), gradients
+    are the incoming gradient for all three operands."""
+    shapes = [(8192, 768), (480, 768), (7, 13)]
+    trips = [tuple(bf(rnd(*sh, seed=300 + 10 * i + j)).requires_grad_(True) for j in range(3)) for i, sh in enumerate(shapes)]
+    outs = ops.add3_group(trips)
+    for (a, b, c), y in zip(trips, outs):
+        ref = (a.float() + b.float() + c.float()).to(torch.bfloat16)
+        assert torch.equal(y, ref)
+    sum(float(i + 1) * o.float().sum() for i, o in enumerate(outs)).backward()
+    for i, (a, b, c) in enumerate(trips):
+        for t in (a, b, c):
+            assert torch.equal(t.grad.float(), torch.full_like(t, float(i + 1)).float())
+
+
 def test_gemm_rejects_bad_shapes():
     a, b = bf(rnd(16, 12)), bf(rnd(8, 12))
     with pytest.raises(RuntimeError, match="granularity"):
