@@ -281,16 +281,18 @@ void colsum_kernel(const ColsumArgs a) {
 // grouped mean over T + concatenation: problem i pools x_i (B, T_i, d) into columns [i d, (i+1) d) of y (B, ldy);
 // one launch for the three modalities (reference models/fusion_layers.py:166-171) instead of three 96-workgroup ones
 struct PoolArgs { const unsigned short* x[MMF_POOL_MAX]; unsigned short* g[MMF_POOL_MAX]; int T[MMF_POOL_MAX]; int blk_start[MMF_POOL_MAX + 1]; int n, B, d, ld; };
-__global__ __launch_bounds__(256)
+constexpr int POOL_THREADS = 1024, POOL_RG = POOL_THREADS / 16;   // 64 row groups x 16 column lanes: the 288 workgroups of
+// a MulT launch are one per CU, so the rows in flight per CU are what sets the rate (256 threads: 1.8 TB/s)
+__global__ __launch_bounds__(POOL_THREADS)
 void meanpool_cat_fwd_kernel(const PoolArgs a, unsigned short* __restrict__ y) {
-  __shared__ float red[16][128 + 4];
+  __shared__ float red[POOL_RG][128 + 4];
   const int i = blockIdx.z, T = a.T[i], d = a.d;
   const int b = blockIdx.x, cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
   const int col = blockIdx.y * 128 + cl * 8;
   float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (col < d) {
     const unsigned short* p = a.x[i] + (size_t)b * T * d + col;
-    for (int t = rg; t < T; t += 16) {
+    for (int t = rg; t < T; t += POOL_RG) {
       const u32x4_t w = *reinterpret_cast<const u32x4_t*>(p + (size_t)t * d);
       s[0] += bf16lo(w[0]); s[1] += bf16hi(w[0]); s[2] += bf16lo(w[1]); s[3] += bf16hi(w[1]);
       s[4] += bf16lo(w[2]); s[5] += bf16hi(w[2]); s[6] += bf16lo(w[3]); s[7] += bf16hi(w[3]);
@@ -304,7 +306,7 @@ void meanpool_cat_fwd_kernel(const PoolArgs a, unsigned short* __restrict__ y) {
     if (c < d) {
       float t = 0.f;
 #pragma unroll
-      for (int g = 0; g < 16; ++g) t += red[g][threadIdx.x];
+      for (int g = 0; g < POOL_RG; ++g) t += red[g][threadIdx.x];
       y[(size_t)b * a.ld + i * d + c] = f32_to_bf16_bits(t / (float)T);
     }
   }
@@ -555,7 +557,7 @@ extern "C" int mmf_meanpool_cat_fwd(const void* const* xs, const int* Ts, int n,
     if (!xs[i] || Ts[i] <= 0 || !mmf_aligned16(xs[i])) MMF_FAIL(MMF_E_SHAPE, "mmf_meanpool_cat_fwd[%d]: bad operand", i);
     a.x[i] = static_cast<const unsigned short*>(xs[i]); a.T[i] = Ts[i];
   }
-  hipLaunchKernelGGL(meanpool_cat_fwd_kernel, dim3(B, (d + 127) / 128, n), dim3(256), 0, static_cast<hipStream_t>(stream), a,
+  hipLaunchKernelGGL(meanpool_cat_fwd_kernel, dim3(B, (d + 127) / 128, n), dim3(POOL_THREADS), 0, static_cast<hipStream_t>(stream), a,
                      static_cast<unsigned short*>(y));
   MMF_CHECK_LAUNCH("mmf_meanpool_cat_fwd");
   return MMF_OK;
