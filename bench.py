@@ -346,6 +346,20 @@ def main():
         ops.set_manual_wgrad_flush(False)
         return g1, gparts, bounds + [arena.numel]
 
+    def try_capture_split(body):
+        """capture_split, or None (with the automatic flush restored) if the three-graph capture fails on this
+        software stack: the run then falls back to the one-graph step + one-shot all-reduce instead of aborting."""
+        from mmfusion import ops
+        try:
+            return capture_split(body)
+        except Exception as e:                                   # noqa: BLE001 - any capture failure means: do not overlap
+            if rank == 0:
+                print(f"bench: overlapped exchange disabled ({type(e).__name__}: {e})", file=sys.stderr, flush=True)
+            ops.set_manual_wgrad_flush(False)
+            ops.take_pending_wgrad()
+            torch.cuda.synchronize()
+            return None
+
     def replay_split(g1, gparts, bounds):
         g1.replay()
         handles = []
@@ -377,8 +391,9 @@ def main():
             eager_step()
             before_replay()
             if overlap:
-                split = capture_split(fwd_bwd)
-            else:
+                split = try_capture_split(fwd_bwd)
+                overlap = split is not None
+            if not overlap:
                 graph = capture(fwd_bwd)
             graph2 = capture(opt_launch)
 
@@ -398,8 +413,9 @@ def main():
         eager_step = make_step(args.workload, model, xs, arena)
         profile_step = eager_step
         if overlap:
-            split = capture_split(eager_step)
-        elif use_graph:
+            split = try_capture_split(eager_step)
+            overlap = split is not None
+        if use_graph and not overlap:
             graph = capture(eager_step)
 
     def run_step_fwdbwd():
