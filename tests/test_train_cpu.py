@@ -25,3 +25,39 @@ def test_fusion_loss_recipe():
     assert torch.allclose(fusion_loss({"emotion_logits": logits, "contrastive_losses": cl}, y), want)
     assert torch.allclose(fusion_loss({"emotion_logits": logits, "contrastive_losses": {}}, y),
                           torch.nn.functional.cross_entropy(logits, y, label_smoothing=0.1))
+
+
+def test_split_wgrad_by_offset_partitions_by_arena_range(monkeypatch):
+    """Host logic of the overlapped data-parallel exchange (bench.py, N > 1): queued wgrad problems are cut into
+    consecutive gradient-arena ranges of about equal GEMM work; problems writing one region stay in one part (the
+    overwrite-then-accumulate order inside it is kept), the bounds are the first offsets of the parts."""
+    from mmfusion import ops
+    offs = {}
+
+    def fake(q):
+        return offs[id(q[2])]
+    monkeypatch.setattr(ops, "wgrad_offset", fake)
+
+    def prob(off, n_out, k_in, rows):
+        dy, x, g = torch.empty(rows, n_out), torch.empty(rows, k_in), torch.empty(n_out, k_in)
+        offs[id(g)] = off
+        return (dy, x, g, None, None, True)
+    # arena order: four equal matrices, one of them written twice (same region), then a small one
+    a, b, b2, c, d, e = (prob(0, 64, 64, 100), prob(4096, 64, 64, 100), prob(4096, 64, 64, 100), prob(8192, 64, 64, 100),
+                         prob(12288, 64, 64, 100), prob(16384, 8, 8, 100))
+    pend = [e, c, b, a, d, b2]                              # queue order is backward order, not arena order
+    parts, bounds = ops.split_wgrad_by_offset(pend, 2)
+    assert len(parts) == 2 and bounds[0] == 0
+    assert [offs[id(q[2])] for q in parts[0]] == sorted(offs[id(q[2])] for q in parts[0])
+    got = [id(q) for p in parts for q in p]
+    assert sorted(got) == sorted(id(q) for q in pend)       # a partition: nothing lost, nothing twice
+    lo = {offs[id(q[2])] for q in parts[0]}
+    hi = {offs[id(q[2])] for q in parts[1]}
+    assert max(lo) < min(hi) == bounds[1]                   # consecutive ranges, bound = first offset of the second part
+    assert (4096 in lo) != (4096 in hi)                     # both writers of the shared region on one side
+    assert [id(q) for q in (parts[0] + parts[1]) if offs[id(q[2])] == 4096] == [id(b), id(b2)]   # queue order kept
+    work = [sum(q[2].numel() * q[0].shape[0] for q in p) for p in parts]
+    assert 0.3 < work[0] / sum(work) < 0.7
+    # more parts than distinct regions: trailing parts are empty, bounds stay monotone
+    parts3, bounds3 = ops.split_wgrad_by_offset([a], 3)
+    assert [len(p) for p in parts3] == [1, 0, 0] and bounds3 == sorted(bounds3)
