@@ -33,6 +33,7 @@ from mmfusion.ops import AttnSpec, LinearSpec, W
 _depth = 0          # >0 while inside an outer fusion forward: the arena was already ensured
 import os as _os
 _BRANCH_STREAM = _os.environ.get("MMF_HIER_STREAMS", "1") != "0"   # HierarchicalFusion: small branches beside MulT
+_MULT_NESTED = _os.environ.get("MMF_MULT_NESTED", "0") == "1"      # A/B: the two groups also when MulT runs inside HierarchicalFusion
 _MULT_STREAMS = int(_os.environ.get("MMF_MULT_STREAMS", "2"))       # MulT's cross blocks as this many concurrent groups (1, 2, 3)
 
 
@@ -279,7 +280,7 @@ class MultimodalTransformer(_FusionBase):
         blocks = [self.text_to_audio, self.text_to_video, self.audio_to_text, self.audio_to_video,
                   self.video_to_text, self.video_to_audio]
         qs, kvs, Tqs, Tks = [t, t, a, a, v, v], [a, v, t, v, t, a], [Tt, Tt, Ta, Ta, Tv, Tv], [Ta, Tv, Tt, Tv, Tt, Ta]
-        if _MULT_STREAMS > 1 and _depth == 1 and t.is_cuda:      # as the root module only: nested in HierarchicalFusion the
+        if _MULT_STREAMS > 1 and (_depth == 1 or _MULT_NESTED) and t.is_cuda:      # as the root module only: nested in HierarchicalFusion the
             # branch stream already fills the holes, and a third stream measured slower (hier-seq 2.90 -> 3.24 ms)
             # The six blocks are independent: as balanced groups on concurrent streams, one group's HBM- / latency-bound
             # launches (attention, LayerNorm, residual adds, the partly filled last round of every GEMM launch) run
