@@ -146,16 +146,28 @@ def _cross_blocks(blocks: Sequence["CrossModalTransformer"], qs: Sequence[torch.
                   p: float = 0.0) -> List[torch.Tensor]:
     """n independent CrossModalTransformer blocks (reference :202-211), one launch per stage.
     qs[i]: bf16 (B*Tq_i, d); kvs[i]: bf16 (B*Tk_i, d)."""
-    mp0 = blocks[0].attention
-    d, H, dh = mp0.embed_dim, mp0.num_heads, mp0.head_dim
+    proj = _cross_in_proj(blocks, qs, kvs)                           # [Q0, KV0, Q1, KV1, ...]
+    att = _cross_attention(blocks, proj, B, Tqs, Tks, p)
+    return _cross_tail(blocks, att, qs, p)
+
+
+def _cross_in_proj(blocks, qs, kvs) -> List[torch.Tensor]:
     items = []
     for blk, q, kv in zip(blocks, qs, kvs):
         items.append((q, blk.attention.q_spec(), None))
         items.append((kv, blk.attention.kv_spec(), None))
-    proj = ops.linear_group(items)                                   # [Q0, KV0, Q1, KV1, ...]
+    return ops.linear_group(items)
+
+
+def _cross_attention(blocks, proj, B, Tqs, Tks, p) -> List[torch.Tensor]:
+    mp0 = blocks[0].attention
+    d, H, dh = mp0.embed_dim, mp0.num_heads, mp0.head_dim
     specs = [AttnSpec(B, Tqs[i], Tks[i], q=(2 * i, 0), k=(2 * i + 1, 0), v=(2 * i + 1, d))
              for i in range(len(blocks))]
-    att = ops.attention_group(specs, H, dh, proj, dropout_p=p)              # dropout(p) on the probabilities
+    return ops.attention_group(specs, H, dh, proj, dropout_p=p)             # dropout(p) on the probabilities
+
+
+def _cross_tail(blocks, att, qs, p) -> List[torch.Tensor]:
     pre1 = ops.linear_group([(att[i], _lin(blk.attention.out_proj), qs[i]) for i, blk in enumerate(blocks)])
     x = ops.layernorm_group([(pre1[i], blk.norm1.weight, blk.norm1.bias) for i, blk in enumerate(blocks)],
                             blocks[0].norm1.eps)
