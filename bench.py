@@ -311,6 +311,9 @@ def main():
     # MMF_DP_OVERLAP=0 keeps the one-graph step followed by the whole-arena all-reduce.
     overlap = world > 1 and use_graph and os.environ.get("MMF_DP_OVERLAP", "1") != "0"
     compress = None if args.allreduce == "fp32" else "bf16"
+    # number of wgrad parts / arena ranges (MMF_DP_PARTS, default 2): more parts hide more of the exchange under the
+    # remaining wgrad launches and pay one more partly filled launch each; to be tuned against the scaling runs
+    dp_parts = max(2, min(4, int(os.environ.get("MMF_DP_PARTS", "2"))))
 
     def capture_split(body):
         """-> (graph of `body` with its wgrad problems parked, [graphs of the wgrad parts], [arena range bounds])"""
@@ -318,7 +321,7 @@ def main():
 
         def eager_all():
             body()
-            parts, _ = ops.split_wgrad_by_offset(ops.take_pending_wgrad(), 2)
+            parts, _ = ops.split_wgrad_by_offset(ops.take_pending_wgrad(), dp_parts)
             for part in parts:
                 ops.issue_wgrad(part)
         ops.set_manual_wgrad_flush(True)
@@ -333,7 +336,7 @@ def main():
         with torch.cuda.graph(g1):
             body()
         pend = ops.take_pending_wgrad()                 # operands live in g1's pool; referenced until the parts are captured
-        parts, bounds = ops.split_wgrad_by_offset(pend, 2)
+        parts, bounds = ops.split_wgrad_by_offset(pend, dp_parts)
         gparts = []
         for part in parts:
             g = None
