@@ -1,14 +1,19 @@
 #!/usr/bin/env python3
 """bench.py — fusion fwd+bwd samples/s (BASELINE.json metric) on N MI355X of one node.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload mult|hier] [--no-graph]
-                    [--no-cpu-baseline]
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload mult|hier|train] [--no-graph]
+                    [--no-cpu-baseline] [--frozen-inputs]
+    N > 1: either the driver's `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...`
+    or plain `python bench.py --gpus N`, which starts exactly that launcher as a CHILD process before anything in this
+    process has touched the GPU and relays its output and exit code.
 
 Workload (BASELINE.json configs[1]): MulT cross-modal attention,
 bf16 storage / f32 accumulate, synthetic features text (16,512,768), audio (16,400,768),
 video (16,30,768) ~ N(0,1) from seed 1234+rank (generated in fp32, cast to bf16 once at set-up), default-initialised weights from
-torch.manual_seed(0), fusion_dropout = 0, loss = fused_features.sum().
+torch.manual_seed(0), fusion_dropout = 0, loss = fused_features.sum().  The inputs REQUIRE GRAD (headline): in the
+model they are the outputs of the encoder tails, so the step computes the twelve in-projection dgrads and the sums of
+the per-use input gradients as well.  `--frozen-inputs` times the round-1 variant (no input gradients); at N = 1 the
+default run reports that number too, as `frozen_inputs`, beside the headline.
 
 One "step" = fp32->bf16 weight-shadow cast, gradient-arena zeroing, forward, backward — and, for
 N > 1, the RCCL all-reduce (mean) of the flat gradient arena, the path's one exchange step.
@@ -18,8 +23,15 @@ hipGraph unless --no-graph.  Rank 0 prints ONE JSON line.
 roofline: HIP-event durations of every grouped GEMM / attention launch are collected in a
 separate eager pass after the timed region (same process, same shapes); the dominant kernel is
 the label with the largest total time; achieved = its algorithmic FLOPs / its time.
+step_tflops = the algorithmic FLOPs of the GEMM / attention problems ACTUALLY launched in one step (summed per launch
+in that pass: 2MNK per GEMM problem, 4 / 8 Tq Tk d per attention problem fwd / bwd) / step time.
 cpu_baseline: oracle/ref_cpu.py (fp32, all host cores) timed on rank 0 at N = 1 on the same
 workload: 1 warm-up + best of 2 steps.
+
+Collectives and rank-0-only work: every rank leaves the process group (barrier, destroy_process_group) right after the
+timed region and the max-over-ranks reduction; rank 0's per-kernel pass, CPU baseline and printing run AFTER that, so
+no rank-0-only region can contain a collective the other ranks are not in (the cause of both round-1 hangs,
+DESIGN.md section 6) — with the group gone, mmfusion.dp's exchanges are no-ops instead of deadlocks.
 """
 import argparse
 import json
@@ -49,7 +61,7 @@ def mult_flops_per_sample(Tt, Ta, Tv, d):
     return cross + selfa + 6 * d * d
 
 
-def build(workload, device, rank, dropout=0.0):
+def build(workload, device, rank, dropout=0.0, input_grads=True):
     import config as cfgmod
     from mmfusion import synth
     from models import fusion_layers as fl
@@ -78,6 +90,9 @@ def build(workload, device, rank, dropout=0.0):
     # step's inputs are the bf16 tensors resident in HBM
     xs = [t.to(device).to(torch.bfloat16) for t in synth.make_features(S["B"], (S["T_text"], S["T_audio"], S["T_frames"]),
                                                                      S["d"], seed=synth.INPUT_SEED + rank)]
+    if input_grads:            # the encoder tails upstream need d(loss)/d(features): bf16 leaves that require grad
+        for x in xs:
+            x.requires_grad_(True)
     return cfg, model, xs
 
 
@@ -90,19 +105,27 @@ def make_train_step(model, xs, arena, world, allreduce, rank):
     g = torch.Generator().manual_seed(99 + rank)
     labels = torch.randint(0, 7, (xs[0].shape[0],), generator=g).to(xs[0].device)
 
+    opt.set_schedule(1e-4, 100000)       # OneCycleLR evaluated on the device by opt.advance(), inside the captured step
+
     def fwd_bwd():
         arena.zero_grad(overlap=True, lazy=True)
+        for x in xs:
+            x.grad = None                # input gradients are produced anew each step, not accumulated across steps
         out = model(*xs, compute_contrastive_loss=True)
         fusion_loss(out, labels).backward()
         arena.finalize_grads()
 
-    def before_replay():
-        opt.set_hparams(lr=one_cycle_lr(opt.t, 100000, 1e-4))
+    def before_replay():                 # nothing crosses the host per step any more (pinned-buffer race)
+        pass
+
+    def opt_launch():
+        opt.advance()
+        opt.launch()
 
     def exchange():
         if world > 1:
             dp.allreduce_grads(arena, compress=None if allreduce == "fp32" else "bf16")
-    return fwd_bwd, before_replay, exchange, opt.launch
+    return fwd_bwd, before_replay, exchange, opt_launch
 
 
 def make_step(workload, model, xs, arena):
@@ -112,6 +135,8 @@ def make_step(workload, model, xs, arena):
         # zeroed lazily: vectors by memset, matrices by the first wgrad GEMM of the step overwriting
         # (ParamArena.zero_grad(lazy=True); finalize_grads() zeroes any matrix no wgrad wrote)
         arena.zero_grad(overlap=True, lazy=True)
+        for x in xs:
+            x.grad = None                # input gradients are produced anew each step, not accumulated across steps
         if workload == "mult":
             out = model(*xs)
             loss = out["fused_features"].sum()
@@ -194,30 +219,32 @@ _SYMBOL = {"gemm4_grouped_kernel<NT,bf16>": ["gemm4_grouped_kernel<false, false,
 
 
 def pmc_lookup(label):
-    """(HBM bytes per launch, MFMA utilisation) of a bench kernel label from the committed PMC passes
+    """(HBM bytes per launch, MFMA utilisation, source file) of a bench kernel label from the committed PMC passes
     (profiles/*_pmc_traffic.json, written by tools/pmc_summary.py from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE /
     SQ_VALU_MFMA_BUSY_CYCLES runs of this same workload, FETCH_SIZE x2 for gfx950).  bench.py cannot profile
-    itself, hence the file; (None, None) if absent.  A label that covers two kernel generations (NT/NN: 256x256
-    and 256x128 tiles) reports the launch-weighted mean; the two backward attention kernels are summed."""
+    itself, hence the file — the JSON line names it as the `source` of these two fields; (None, None, None) if
+    absent.  A label that covers two kernel generations (NT/NN: 256x256 and 256x128 tiles) reports the
+    launch-weighted mean; the two backward attention kernels are summed."""
     import glob
     files = sorted(glob.glob(os.path.join(REPO, "profiles", "*_pmc_traffic.json")))
     if not files or label not in _SYMBOL:
-        return None, None
+        return None, None, None
+    src = os.path.relpath(files[-1], REPO)
     try:
         with open(files[-1]) as f:
             K = json.load(f)["kernels"]
         hits = [K[s] for s in _SYMBOL[label] if s in K]
         if not hits:
-            return None, None
+            return None, None, None
         if label.startswith("attn_bwd"):
-            return int(sum(h["hbm_bytes_per_launch"] for h in hits)), None
+            return int(sum(h["hbm_bytes_per_launch"] for h in hits)), None, src
         n = sum(h["launches"] for h in hits)
         traffic = int(sum(h["hbm_bytes_per_launch"] * h["launches"] for h in hits) / n)
         utils = [(h["mfma_util"], h["launches"]) for h in hits if "mfma_util" in h]
         util = round(sum(u * c for u, c in utils) / sum(c for _, c in utils), 4) if utils else None
-        return traffic, util
+        return traffic, util, src
     except (OSError, ValueError, KeyError):
-        return None, None
+        return None, None, None
 
 
 def kernel_profile(step, nsteps):
@@ -241,16 +268,69 @@ def kernel_profile(step, nsteps):
     return {k: {"ms_total": v[0], "flops_total": v[1], "launches": v[2], "bytes_total": v[3]} for k, v in agg.items()}
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(n, argv):
+    """`python bench.py --gpus N` outside a launcher: start N ranks with torch.distributed.run as a CHILD process and
+    relay its exit code (rank 0's JSON line goes straight to the inherited stdout).  Called before this process has
+    made any GPU call (torch.cuda.device_count() does not initialise the GPU on this image); the launcher is never
+    exec'ed into a process that has touched the GPU."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+           "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def timed_region(run_step, steps, warmup, world, dist=None, sync=lambda: None, reduce_device="cpu"):
+    """The contract's timed region: W untimed steps, then exactly K steps bracketed by barrier + device sync on both
+    sides; returns the MAX over ranks of the elapsed seconds.  Every rank runs this, collectives included."""
+    for _ in range(warmup):
+        run_step()
+    if world > 1:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run_step()
+    sync()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=reduce_device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
+def leave_group(world, dist=None):
+    """All ranks: barrier, then destroy the process group.  Whatever runs after this (rank 0's per-kernel pass, CPU
+    baseline, printing) cannot contain a collective: torch.distributed is no longer initialised, so mmfusion.dp's
+    exchanges see a world of one and return instead of waiting for ranks that are not there."""
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", choices=["mult", "hier", "train"], default="mult",
                     help="mult: MulT fwd+bwd (BASELINE configs[1], the headline); hier: hier-seq fwd+bwd "
                          "(configs[2]); train: hier-seq training step incl. fused clip+AdamW (configs[3])")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--frozen-inputs", action="store_true",
+                    help="inputs do not require grad (round-1 variant: no in-projection dgrads, no input-gradient sums)")
     ap.add_argument("--profile-steps", type=int, default=5)
     ap.add_argument("--dropout", type=float, default=0.0,
                     help="fusion_dropout (headline = 0, the parity-comparable setting; 0.1 = reference default)")
@@ -261,12 +341,19 @@ def main():
                     help="wire dtype of the gradient all-reduce for N > 1 (compute and accumulation stay as is)")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # not under a launcher: become one (child process), before any GPU call in this process
+        ndev = torch.cuda.device_count()
+        if args.backend == "nccl" and ndev < args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but {ndev} GPU(s) visible on this node")
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     ndev = torch.cuda.device_count()
@@ -285,10 +372,21 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from mmfusion import arena as arena_mod, dp, synth
-    cfg, model, xs = build(args.workload, device, rank, args.dropout)
+    cfg, model, xs = build(args.workload, device, rank, args.dropout, input_grads=not args.frozen_inputs)
     arena = arena_mod.ensure(model)
     use_graph = not args.no_graph
-    graph = graph2 = None
+    compress = None if args.allreduce == "fp32" else "bf16"
+    # N > 1: put the first half of the gradient arena on the wire while the second half of the deferred weight-gradient
+    # launches is still computing.  The step is captured as three graphs sharing one memory pool — forward + backward
+    # with the wgrad problems parked (ops.set_manual_wgrad_flush), then the two halves of the wgrad flush split by
+    # gradient-arena offset — and the all-reduce of a finished arena range is started between the replays
+    # (dp.allreduce_grads_range_async: RCCL's own stream, behind what the compute stream has enqueued so far).
+    # MMF_DP_OVERLAP=0 keeps the one-graph step followed by the whole-arena all-reduce.
+    want_overlap = world > 1 and use_graph and os.environ.get("MMF_DP_OVERLAP", "1") != "0"
+    # number of wgrad parts / arena ranges (MMF_DP_PARTS, default 2): more parts hide more of the exchange under the
+    # remaining wgrad launches and pay one more partly filled launch each; to be tuned against the scaling runs
+    dp_parts = max(2, min(4, int(os.environ.get("MMF_DP_PARTS", "2"))))
+    fallback = {"reason": None}
 
     def capture(fn):
         side = torch.cuda.Stream()
@@ -302,18 +400,6 @@ def main():
         with torch.cuda.graph(g):
             fn()
         return g
-
-    # N > 1: put the first half of the gradient arena on the wire while the second half of the deferred weight-gradient
-    # launches is still computing.  The step is captured as three graphs sharing one memory pool — forward + backward
-    # with the wgrad problems parked (ops.set_manual_wgrad_flush), then the two halves of the wgrad flush split by
-    # gradient-arena offset — and the all-reduce of a finished arena range is started between the replays
-    # (dp.allreduce_grads_range_async: RCCL's own stream, behind what the compute stream has enqueued so far).
-    # MMF_DP_OVERLAP=0 keeps the one-graph step followed by the whole-arena all-reduce.
-    overlap = world > 1 and use_graph and os.environ.get("MMF_DP_OVERLAP", "1") != "0"
-    compress = None if args.allreduce == "fp32" else "bf16"
-    # number of wgrad parts / arena ranges (MMF_DP_PARTS, default 2): more parts hide more of the exchange under the
-    # remaining wgrad launches and pay one more partly filled launch each; to be tuned against the scaling runs
-    dp_parts = max(2, min(4, int(os.environ.get("MMF_DP_PARTS", "2"))))
 
     def capture_split(body):
         """-> (graph of `body` with its wgrad problems parked, [graphs of the wgrad parts], [arena range bounds])"""
@@ -351,13 +437,15 @@ def main():
 
     def try_capture_split(body):
         """capture_split, or None (with the automatic flush restored) if the three-graph capture fails on this
-        software stack: the run then falls back to the one-graph step + one-shot all-reduce instead of aborting."""
+        software stack: the run then falls back to the one-graph step + one-shot all-reduce instead of aborting.
+        The reason goes into the JSON line (config.overlap_fallback), not only to stderr."""
         from mmfusion import ops
         try:
             return capture_split(body)
         except Exception as e:                                   # noqa: BLE001 - any capture failure means: do not overlap
+            fallback["reason"] = f"{type(e).__name__}: {e}"[:300]
             if rank == 0:
-                print(f"bench: overlapped exchange disabled ({type(e).__name__}: {e})", file=sys.stderr, flush=True)
+                print(f"bench: overlapped exchange disabled ({fallback['reason']})", file=sys.stderr, flush=True)
             ops.set_manual_wgrad_flush(False)
             ops.take_pending_wgrad()
             torch.cuda.synchronize()
@@ -373,87 +461,69 @@ def main():
         for h in handles:
             h.finish()
 
-    if args.workload == "train":
-        fwd_bwd, before_replay, exchange, opt_launch = make_train_step(model, xs, arena, world, args.allreduce, rank)
+    def make_runner(model, xs, arena):
+        """-> (run_step: one timed step incl. the exchange, profile_step: the same work WITHOUT any collective, overlap flag)"""
+        overlap = want_overlap
+        graph = graph2 = split = None
+        if args.workload == "train":
+            fwd_bwd, before_replay, exchange, opt_launch = make_train_step(model, xs, arena, world, args.allreduce, rank)
 
-        def eager_step():
-            before_replay()
-            fwd_bwd()
-            exchange()
-            opt_launch()
-
-        def profile_step():            # rank 0's per-kernel timing pass: no collective (the other ranks are not in it)
-            before_replay()
-            fwd_bwd()
-            opt_launch()
-        if use_graph:                       # two graphs: the all-reduce sits between backward and AdamW
-            # one eager step first: its AdamW launch has written the bf16 shadow (ParamArena.mark_shadow_fresh), so the
-            # forward captured below holds no fp32->bf16 weight cast — every replayed step's shadow comes from the
-            # optimiser kernel of the step before, as in FusionTrainStep (a capture taken before any optimiser launch
-            # recorded the 124 us whole-arena cast into every step although nothing read its result first)
-            eager_step()
-            before_replay()
-            if overlap:
-                split = try_capture_split(fwd_bwd)
-                overlap = split is not None
-            if not overlap:
-                graph = capture(fwd_bwd)
-            graph2 = capture(opt_launch)
-
-        def run_step():
-            if overlap:
-                before_replay()
-                replay_split(*split)
-                graph2.replay()
-            elif graph is not None:
-                before_replay()
-                graph.replay()
+            def eager_step():
+                fwd_bwd()
                 exchange()
-                graph2.replay()
-            else:
+                opt_launch()
+
+            def profile_step():            # per-kernel timing pass: no collective
+                fwd_bwd()
+                opt_launch()
+            if use_graph:                       # two graphs: the all-reduce sits between backward and AdamW
+                # one eager step first: its AdamW launch has written the bf16 shadow (ParamArena.mark_shadow_fresh), so the
+                # forward captured below holds no fp32->bf16 weight cast — every replayed step's shadow comes from the
+                # optimiser kernel of the step before, as in FusionTrainStep
                 eager_step()
-    else:
+                if overlap:
+                    split = try_capture_split(fwd_bwd)
+                    overlap = split is not None
+                if not overlap:
+                    graph = capture(fwd_bwd)
+                graph2 = capture(opt_launch)
+
+            def run_step():
+                if overlap:
+                    replay_split(*split)
+                    graph2.replay()
+                elif graph is not None:
+                    graph.replay()
+                    exchange()
+                    graph2.replay()
+                else:
+                    eager_step()
+            return run_step, profile_step, overlap
         eager_step = make_step(args.workload, model, xs, arena)
-        profile_step = eager_step
         if overlap:
             split = try_capture_split(eager_step)
             overlap = split is not None
         if use_graph and not overlap:
             graph = capture(eager_step)
 
-    def run_step_fwdbwd():
-        if overlap:
-            replay_split(*split)
-            return
-        if graph is not None:
-            graph.replay()
-        else:
-            eager_step()
-        if world > 1:
-            # bucketed RCCL all-reduce (mean) of the flat gradient arena
-            dp.allreduce_grads(arena, compress=None if args.allreduce == "fp32" else "bf16")
-    if args.workload != "train":
-        run_step = run_step_fwdbwd
+        def run_step():
+            if overlap:
+                replay_split(*split)
+                return
+            if graph is not None:
+                graph.replay()
+            else:
+                eager_step()
+            if world > 1:
+                dp.allreduce_grads(arena, compress=compress)        # bucketed RCCL all-reduce (mean) of the flat gradient arena
+        return run_step, eager_step, overlap
 
+    run_step, profile_step, overlap = make_runner(model, xs, arena)
     if world > 1:                       # communicator set-up and the first collective's lazy work stay out of the timed region
         dist.all_reduce(torch.zeros(64, device=device))
         torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        run_step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run_step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = timed_region(run_step, args.steps, args.warmup, world, dist, torch.cuda.synchronize,
+                           device if args.backend == "nccl" else "cpu")
 
     # optional (MMF_BENCH_CHECKSUM=1): f64 |.|-sum and sum of the gradient arena after the last timed step, to compare
     # exchange schedules (overlapped vs one-shot all-reduce) on the same inputs
@@ -461,71 +531,87 @@ def main():
     if os.environ.get("MMF_BENCH_CHECKSUM"):
         g64 = arena.grads.double()
         checksum = [float(g64.abs().sum()), float(g64.sum())]
+    # ---- every rank leaves the group HERE; nothing below can wait for another rank ----
+    leave_group(world, dist)
+    if rank != 0:
+        return
     S = synth.C2_SHAPES
     B = S["B"]
     ms_per_step = elapsed / args.steps * 1e3
     value = world * B * args.steps / elapsed
 
-    if rank == 0:
-        # per-kernel HIP-event timing runs with the stream concurrency of the timed steps switched off (MulT's two
-        # block groups, HierarchicalFusion's branch stream): a kernel that shares the chip with another stream's
-        # kernel would be charged the other's time.  The dominant kernel (the deferred wgrad launch) runs after the
-        # join either way, so its duration is the same in both modes (and in the rocprofv3 summary).
-        from models import fusion_layers as _fl
-        _fl._MULT_STREAMS, _fl._BRANCH_STREAM = 1, False
-        prof = kernel_profile(profile_step, args.profile_steps)
-        dom = max(prof, key=lambda k: prof[k]["ms_total"])
-        dsec = prof[dom]["ms_total"] * 1e-3
-        ach = prof[dom]["flops_total"] / dsec / 1e12
-        # the committed PMC passes are of the MulT workload: its per-launch byte counts do not describe the other workloads' launches
-        traffic, mfma_util = pmc_lookup(dom) if args.workload == "mult" else (None, None)
-        roofline = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": BF16_MFMA_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                    "mfma_util_pmc": mfma_util,
-                    "avg_launch_us": round(prof[dom]["ms_total"] * 1e3 / prof[dom]["launches"], 2),
-                    "launches_per_step": prof[dom]["launches"] // args.profile_steps}
-        kernels = {k: {"us_per_step": round(v["ms_total"] * 1e3 / args.profile_steps, 1),
-                       "tflops": round(v["flops_total"] / (v["ms_total"] * 1e-3) / 1e12, 1) if v["ms_total"] > 0 else None,
-                       "launches_per_step": v["launches"] // args.profile_steps} for k, v in sorted(prof.items())}
-        fwd_flops = mult_flops_per_sample(S["T_text"], S["T_audio"], S["T_frames"], S["d"])
-        line = {
-            "metric": "fusion fwd+bwd samples/sec at B=16 d=768", "value": round(value, 2), "unit": "samples/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
-            "data": "synthetic",
-            "config": {"workload": {"mult": "MulT fwd+bwd", "hier": "hier-seq fwd+bwd",
-                                    "train": "hier-seq training step (fwd+bwd+clip+AdamW)"}[args.workload] +
-                                   f", B=16/GPU, T_text=512 T_audio=400 T_frames=30 d=768 H=8, fusion_dropout={args.dropout:g}",
-                       "global_batch": B * world, "parallelism": f"dp{world}",
-                       "grad_allreduce": (args.allreduce if world > 1 else None), "allreduce_overlaps_wgrad": bool(overlap),
-                       "graph_replay": bool(use_graph)},
-            "step_tflops": round(3 * fwd_flops * B / (ms_per_step * 1e-3) / 1e12, 1) if args.workload == "mult" else None,
-            "roofline": roofline,
-            "kernels": kernels,
-        }
-        af = prof.get("attn_fwd_kernel<96>")
-        if af and af["ms_total"] > 0:
-            # the north_star's named kernel: the MulT attention cores.  At these shapes the cores sit below the
-            # 312 FLOP/B ridge (123-256 FLOP/B), so both roofs are reported: algorithmic FLOPs vs the bf16 MFMA peak
-            # and algorithmic bytes (Q, K, V in, O out, once each) vs the HBM peak.
-            sec = af["ms_total"] * 1e-3
-            traffic, util = pmc_lookup("attn_fwd_kernel<96>")
-            line["roofline_attention_fwd"] = {
-                "kernel": "attn_fwd2_kernel<96> (all nine MulT attention cores, 2 launches)",
-                "mfma": {"achieved": round(af["flops_total"] / sec / 1e12, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(af["flops_total"] / sec / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4)},
-                "hbm": {"achieved": round(af["bytes_total"] / sec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(af["bytes_total"] / sec / 1e9 / HBM_PEAK_GBS, 4)},
-                "traffic": traffic, "mfma_util_pmc": util,
-                "avg_launch_us": round(af["ms_total"] * 1e3 / af["launches"], 2)}
-        if world == 1 and not args.no_cpu_baseline and args.workload == "mult":
-            line["cpu_baseline"] = cpu_baseline(args.workload)
-        if checksum is not None:
-            line["grad_checksum"] = checksum
-        print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    # per-kernel HIP-event timing runs with the stream concurrency of the timed steps switched off (MulT's two
+    # block groups, HierarchicalFusion's branch stream): a kernel that shares the chip with another stream's
+    # kernel would be charged the other's time.  The dominant kernel (the deferred wgrad launch) runs after the
+    # join either way, so its duration is the same in both modes (and in the rocprofv3 summary).
+    from models import fusion_layers as _fl
+    saved_streams = (_fl._MULT_STREAMS, _fl._BRANCH_STREAM)
+    _fl._MULT_STREAMS, _fl._BRANCH_STREAM = 1, False
+    prof = kernel_profile(profile_step, args.profile_steps)
+    _fl._MULT_STREAMS, _fl._BRANCH_STREAM = saved_streams
+    dom = max(prof, key=lambda k: prof[k]["ms_total"])
+    dsec = prof[dom]["ms_total"] * 1e-3
+    ach = prof[dom]["flops_total"] / dsec / 1e12
+    # the committed PMC passes are of the MulT workload: its per-launch byte counts do not describe the other workloads' launches
+    traffic, mfma_util, pmc_src = pmc_lookup(dom) if args.workload == "mult" else (None, None, None)
+    roofline = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": BF16_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                "mfma_util_pmc": mfma_util, "traffic_and_util_source": pmc_src,
+                "avg_launch_us": round(prof[dom]["ms_total"] * 1e3 / prof[dom]["launches"], 2),
+                "launches_per_step": prof[dom]["launches"] // args.profile_steps}
+    kernels = {k: {"us_per_step": round(v["ms_total"] * 1e3 / args.profile_steps, 1),
+                   "tflops": round(v["flops_total"] / (v["ms_total"] * 1e-3) / 1e12, 1) if v["ms_total"] > 0 else None,
+                   "gflop_per_step": round(v["flops_total"] / args.profile_steps / 1e9, 1),
+                   "launches_per_step": v["launches"] // args.profile_steps} for k, v in sorted(prof.items())}
+    launched_flops = sum(v["flops_total"] for v in prof.values()) / args.profile_steps
+    line = {
+        "metric": "fusion fwd+bwd samples/sec at B=16 d=768", "value": round(value, 2), "unit": "samples/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+        "data": "synthetic",
+        "config": {"workload": {"mult": "MulT fwd+bwd", "hier": "hier-seq fwd+bwd",
+                                "train": "hier-seq training step (fwd+bwd+clip+AdamW)"}[args.workload] +
+                               f", B=16/GPU, T_text=512 T_audio=400 T_frames=30 d=768 H=8, fusion_dropout={args.dropout:g}",
+                   "input_gradients": not args.frozen_inputs,
+                   "global_batch": B * world, "parallelism": f"dp{world}",
+                   "grad_allreduce": (args.allreduce if world > 1 else None), "allreduce_overlaps_wgrad": bool(overlap),
+                   "overlap_fallback": fallback["reason"], "graph_replay": bool(use_graph)},
+        # algorithmic FLOPs of the GEMM / attention problems actually launched in one step / step time
+        "step_gflop_launched": round(launched_flops / 1e9, 1),
+        "step_tflops": round(launched_flops / (ms_per_step * 1e-3) / 1e12, 1),
+        "roofline": roofline,
+        "kernels": kernels,
+    }
+    af = prof.get("attn_fwd_kernel<96>")
+    if af and af["ms_total"] > 0:
+        # the north_star's named kernel: the MulT attention cores.  At these shapes the cores sit below the
+        # 312 FLOP/B ridge (123-256 FLOP/B), so both roofs are reported: algorithmic FLOPs vs the bf16 MFMA peak
+        # and algorithmic bytes (Q, K, V in, O out, once each) vs the HBM peak.
+        sec = af["ms_total"] * 1e-3
+        traffic, util, pmc_src = pmc_lookup("attn_fwd_kernel<96>")
+        line["roofline_attention_fwd"] = {
+            "kernel": "attn_fwd2_kernel<96> (all nine MulT attention cores, 2 launches)",
+            "mfma": {"achieved": round(af["flops_total"] / sec / 1e12, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(af["flops_total"] / sec / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4)},
+            "hbm": {"achieved": round(af["bytes_total"] / sec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(af["bytes_total"] / sec / 1e9 / HBM_PEAK_GBS, 4)},
+            "traffic": traffic, "mfma_util_pmc": util, "traffic_and_util_source": pmc_src,
+            "avg_launch_us": round(af["ms_total"] * 1e3 / af["launches"], 2)}
+    if world == 1 and args.workload == "mult" and not args.frozen_inputs and not os.environ.get("MMF_BENCH_NO_FROZEN"):
+        # the round-1 variant beside the headline: same step with inputs that do not require grad
+        _, model2, xs2 = build(args.workload, device, rank, args.dropout, input_grads=False)
+        arena2 = arena_mod.ensure(model2)
+        run2, _, _ = make_runner(model2, xs2, arena2)
+        e2 = timed_region(run2, args.steps, args.warmup, 1, None, torch.cuda.synchronize)
+        line["frozen_inputs"] = {"value": round(B * args.steps / e2, 2), "unit": "samples/s",
+                                 "ms_per_step": round(e2 / args.steps * 1e3, 4),
+                                 "note": "inputs without requires_grad: no in-projection dgrads, no input-gradient sums"}
+        del model2, xs2, arena2, run2
+    if world == 1 and not args.no_cpu_baseline and args.workload == "mult":
+        line["cpu_baseline"] = cpu_baseline(args.workload)
+    if checksum is not None:
+        line["grad_checksum"] = checksum
+    print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

@@ -333,6 +333,11 @@ int mmf_rowmask_apply(const float* x, const float* mask, float* y, int B, int d,
  * new values).
  * ------------------------------------------------------------------------------------------ */
 int mmf_sqnorm_f32(const float* x, int64_t n, float* out, void* stream);
+/* Device-side schedule (graph-capturable): *step += 1, then hparams[5], [6] = 1 - beta^step and, for sched[0] == 1,
+ * hparams[0] = OneCycleLR(cos) learning rate of optimiser step (*step - 1) — torch.optim.lr_scheduler.OneCycleLR as
+ * the reference configures it (training/advanced_trainer.py:102-110).  sched = {mode, max_lr, total_steps, pct_start,
+ * div_factor, final_div_factor} as doubles on the device; mode 0 leaves hparams[0] alone. */
+int mmf_adamw_advance(int64_t* step, float* hparams, const double* sched, void* stream);
 int mmf_adamw_step(float* master, const float* grad, float* exp_avg, float* exp_avg_sq, void* shadow_bf16,
                    int64_t n, const float* hparams, const float* gnorm_sq, void* stream);
 

@@ -75,6 +75,38 @@ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __r
   }
 }
 
+// Device-resident step counter + schedule: ONE thread advances the optimiser's step count and derives this step's
+// learning rate and bias corrections into the hyper-parameter array the update kernel reads, so nothing about a
+// step's hyper-parameters crosses the PCIe bus and a captured training step replays with the right values however
+// far the host runs ahead (a pinned host buffer rewritten per step is read when the GPU executes the copy, not when
+// the host enqueues it).  sched: [0] mode (0 = constant hp[0], 1 = OneCycleLR cos, three_phase = False)
+// [1] max_lr [2] total_steps [3] pct_start [4] div_factor [5] final_div_factor   (reference recipe
+// training/advanced_trainer.py:102-110).  Arithmetic in double like torch.optim.lr_scheduler.OneCycleLR.
+__global__ void adamw_advance_kernel(long long* __restrict__ step, float* __restrict__ hp,
+                                     const double* __restrict__ sched) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const long long t = *step + 1;                 // number of the optimiser step about to run, 1-based
+  *step = t;
+  const double b1 = hp[1], b2 = hp[2];
+  hp[5] = (float)(1.0 - pow(b1, (double)t));
+  hp[6] = (float)(1.0 - pow(b2, (double)t));
+  if (sched[0] == 1.0) {
+    const double max_lr = sched[1], total = sched[2], pct = sched[3];
+    const double initial = max_lr / sched[4], minimum = initial / sched[5];
+    const double up_end = pct * total - 1.0, down_end = total - 1.0, s = (double)(t - 1);
+    const double kPi = 3.14159265358979323846;
+    double lr;
+    if (s <= up_end || up_end >= down_end) {
+      const double q = up_end > 0.0 ? s / up_end : 1.0;
+      lr = max_lr + (initial - max_lr) / 2.0 * (cos(kPi * q) + 1.0);
+    } else {
+      const double q = fmin(1.0, (s - up_end) / (down_end - up_end));
+      lr = minimum + (max_lr - minimum) / 2.0 * (cos(kPi * q) + 1.0);
+    }
+    hp[0] = (float)lr;
+  }
+}
+
 inline int opt_grid(int64_t n) {
   int64_t g = ((n >> 2) + OPT_THREADS - 1) / OPT_THREADS;
   if (g > 2048) g = 2048;
@@ -88,6 +120,14 @@ extern "C" int mmf_sqnorm_f32(const float* x, int64_t n, float* out, void* strea
   if (!x || !out || !mmf_aligned16(x)) MMF_FAIL(MMF_E_ALIGN, "mmf_sqnorm_f32: null or unaligned pointer");
   hipLaunchKernelGGL(sqnorm_kernel, dim3(opt_grid(n)), dim3(OPT_THREADS), 0, static_cast<hipStream_t>(stream), x, n, out);
   MMF_CHECK_LAUNCH("mmf_sqnorm_f32");
+  return MMF_OK;
+}
+
+extern "C" int mmf_adamw_advance(int64_t* step, float* hparams, const double* sched, void* stream) {
+  if (!step || !hparams || !sched) MMF_FAIL(MMF_E_SHAPE, "mmf_adamw_advance: null pointer");
+  hipLaunchKernelGGL(adamw_advance_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream),
+                     reinterpret_cast<long long*>(step), hparams, sched);
+  MMF_CHECK_LAUNCH("mmf_adamw_advance");
   return MMF_OK;
 }
 

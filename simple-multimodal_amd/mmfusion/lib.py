@@ -26,7 +26,7 @@ SYMBOLS = (
     "mmf_attn_fwd_grouped", "mmf_attn_bwd_grouped", "mmf_layernorm_fwd_grouped",
     "mmf_layernorm_bwd_grouped", "mmf_layernorm_bwd_workspace_bytes", "mmf_cast_f32_to_bf16", "mmf_cast_bf16_to_f32", "mmf_cast_bf16_to_f32_scaled", "mmf_cast_f32_to_bf16_2d", "mmf_add3_bf16", "mmf_add3_grouped",
     "mmf_meanpool_fwd", "mmf_meanpool_bwd", "mmf_meanpool_cat_fwd", "mmf_meanpool_cat_bwd", "mmf_colsum_bf16", "mmf_colsum_grouped", "mmf_relu_bwd_bf16", "mmf_relu_bwd_mixed",
-    "mmf_sqnorm_f32", "mmf_adamw_step", "mmf_skinny_linear_fwd", "mmf_skinny_linear_dgrad",
+    "mmf_sqnorm_f32", "mmf_adamw_step", "mmf_adamw_advance", "mmf_skinny_linear_fwd", "mmf_skinny_linear_dgrad",
     "mmf_gat3_dense_fwd", "mmf_gat3_dense_bwd", "mmf_infonce_fwd", "mmf_infonce_bwd", "mmf_adaptive_combine_fwd",
     "mmf_adaptive_combine_bwd", "mmf_adaptive_attn_weights", "mmf_linear_narrow_fwd", "mmf_linear_narrow_bwd", "mmf_stack3_embed_fwd",
     "mmf_stack3_embed_bwd", "mmf_rowmask_apply", "mmf_zero_ranges_f32",
@@ -146,6 +146,7 @@ def load() -> C.CDLL:
     lib.mmf_rowmask_apply.argtypes = [vp, vp, vp, i32, i32, vp]
     lib.mmf_zero_ranges_f32.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), i32, vp]
     lib.mmf_adamw_step.argtypes = [vp, vp, vp, vp, vp, i64, vp, vp, vp]
+    lib.mmf_adamw_advance.argtypes = [vp, vp, vp, vp]
     for name in SYMBOLS:
         getattr(lib, name)          # AttributeError here = header and .so disagree
     if lib.mmf_version() != 1:

@@ -256,19 +256,46 @@ def join_branch_streams() -> None:
 _WGRAD_SORT = _os.environ.get("MMF_WGRAD_SORT", "k")
 
 
-def _issue_wgrad(pend: List[tuple]) -> None:
-    # (has bias, overwrite) -> problems; overwrite = first wgrad of a lazily-zeroed step (arena.zero_grad(lazy=True))
-    groups: dict = {}
+def _wgrad_rounds(pend: List[tuple]) -> List[List[tuple]]:
+    """Split queued problems into launch rounds such that no two problems of one round write overlapping gradient
+    memory (a weight used twice in one forward, e.g. a shared ``nn.Linear``): the GEMM epilogue's accumulate is a
+    plain read-add-write, so two writers of one region inside ONE grouped launch would race and drop updates.  The
+    k-th writer of a region goes to round k; queue order is kept inside a region, so its first-touch overwrite
+    (lazy zeroing) still runs before its accumulates."""
+    rounds: List[List[tuple]] = []
+    spans: List[Tuple[int, int, int]] = []               # (start, end, round) of every destination placed so far
     for q in pend:
-        groups.setdefault((q[3] is not None, q[5]), []).append(q[:5])
-    # longest tiles first (a tile's duration goes with K = the rows of dy), big outputs first among equals: the
-    # kernel hands tiles to the CUs in this order, so the tail of the launch is made of the short tiles
-    for (has_bias, overwrite), group in sorted(groups.items(), key=lambda kv: (not kv[0][0], not kv[0][1])):
-        if _WGRAD_SORT == "k":
-            group.sort(key=lambda t: (-t[0].shape[0], -(t[2].shape[0] * t[2].shape[1])))
-        else:
-            group.sort(key=lambda t: -(t[2].shape[0] * t[2].shape[1] * t[0].shape[0]))
-        gemm_group(GEMM_TN, group, (0 if overwrite else EPI_ACCUM) | (EPI_COLSUM_A if has_bias else 0))
+        mine = [(q[2].data_ptr(), q[2].data_ptr() + 4 * q[2].numel())]
+        if q[3] is not None:
+            mine.append((q[3].data_ptr(), q[3].data_ptr() + 4 * q[3].numel()))
+        r = 0
+        for a, b in mine:
+            for s0, e0, r0 in spans:
+                if a < e0 and s0 < b:
+                    r = max(r, r0 + 1)
+        for a, b in mine:
+            spans.append((a, b, r))
+        while len(rounds) <= r:
+            rounds.append([])
+        rounds[r].append(q)
+    return rounds
+
+
+def _issue_wgrad(pend: List[tuple]) -> None:
+    for rnd in _wgrad_rounds(pend):
+        # (has bias, overwrite) -> problems; overwrite = first wgrad of a lazily-zeroed step (arena.zero_grad(lazy=True))
+        groups: dict = {}
+        for q in rnd:
+            groups.setdefault((q[3] is not None, q[5]), []).append(q[:5])
+        # longest tiles first (a tile's duration goes with K = the rows of dy), big outputs first among equals: the
+        # kernel hands tiles to the CUs in this order, so the tail of the launch is made of the short tiles.
+        # Overwrite groups before accumulate groups.
+        for (has_bias, overwrite), group in sorted(groups.items(), key=lambda kv: (not kv[0][1], not kv[0][0])):
+            if _WGRAD_SORT == "k":
+                group.sort(key=lambda t: (-t[0].shape[0], -(t[2].shape[0] * t[2].shape[1])))
+            else:
+                group.sort(key=lambda t: -(t[2].shape[0] * t[2].shape[1] * t[0].shape[0]))
+            gemm_group(GEMM_TN, group, (0 if overwrite else EPI_ACCUM) | (EPI_COLSUM_A if has_bias else 0))
 
 
 def _issue_wgrad_side(pend: List[tuple]) -> None:

@@ -42,7 +42,20 @@ def one_cycle_lr(step: int, total_steps: int, max_lr: float, pct_start: float = 
 
 
 class FusedAdamW:
-    """AdamW + global-norm clipping over a ``ParamArena`` (all parameters in one launch)."""
+    """AdamW + global-norm clipping over a ``ParamArena`` (all parameters in one launch).
+
+    Hyper-parameters live in a device array.  Two ways to advance a step:
+
+      * ``advance()`` — device-side (graph-capturable): one thread of ``mmf_adamw_advance`` increments the
+        device-resident step counter and derives the bias corrections and, with ``set_schedule``, the OneCycle
+        learning rate.  Nothing crosses the PCIe bus per step, so a captured step replays correctly however far
+        the host runs ahead.  ``self.t`` is the host's mirror of the counter (no read-back).
+      * ``set_hparams(lr)`` — host-side, for a learning rate the host computes: the values go through a RING of
+        pinned buffers, each guarded by an event recorded behind its copy, so a buffer is never rewritten while
+        an asynchronous copy may still read it (the advisor's round-1 finding: one pinned buffer rewritten every
+        step is read when the GPU executes the copy, not when the host enqueues it)."""
+
+    _RING = 32
 
     def __init__(self, arena: ParamArena, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8,
                  weight_decay: float = 1e-5, max_grad_norm: Optional[float] = 1.0):
@@ -53,20 +66,55 @@ class FusedAdamW:
         self.exp_avg_sq = torch.zeros_like(arena.master)
         self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
         self.hparams = torch.zeros(9, dtype=torch.float32, device=dev)
-        self._hp_host = torch.zeros(9, dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.zeros(9)
+        self.step_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.sched = torch.zeros(6, dtype=torch.float64, device=dev)
+        self._cuda = dev.type == "cuda"
+        self._ring = [torch.zeros(9, dtype=torch.float32).pin_memory() if self._cuda else torch.zeros(9)
+                      for _ in range(self._RING)]
+        self._ring_events = [None] * self._RING
+        self._ring_pos = 0
         self.t = 0
+        self._upload(self._static_hparams(lr, 1.0))
+
+    def _static_hparams(self, lr: float, grad_scale: float):
+        b1, b2 = self.betas
+        return [lr, b1, b2, self.eps, self.weight_decay, 1.0 - b1 ** max(self.t, 1), 1.0 - b2 ** max(self.t, 1),
+                self.max_grad_norm if self.max_grad_norm else 0.0, grad_scale]
+
+    def _upload(self, values) -> None:
+        i = self._ring_pos
+        self._ring_pos = (i + 1) % self._RING
+        ev = self._ring_events[i]
+        if ev is not None:
+            ev.synchronize()                 # the copy that last read this buffer has executed (normally long ago)
+        h = self._ring[i]
+        for k, v in enumerate(values):
+            h[k] = v
+        self.hparams.copy_(h, non_blocking=True)
+        if self._cuda:
+            ev = ev or torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self._ring_events[i] = ev
+
+    def set_schedule(self, max_lr: float, total_steps: int, pct_start: float = 0.1, div_factor: float = 25.0,
+                     final_div_factor: float = 1e4) -> None:
+        """OneCycleLR(cos) evaluated on the device by ``advance()`` (reference advanced_trainer.py:102-110)."""
+        self.sched.copy_(torch.tensor([1.0, max_lr, float(total_steps), pct_start, div_factor, final_div_factor],
+                                      dtype=torch.float64))
+
+    def advance(self) -> None:
+        """Device-side step advance (graph-capturable): counter += 1, bias corrections, scheduled LR."""
+        self.t += 1
+        lib.check(lib.load().mmf_adamw_advance(self.step_dev.data_ptr(), self.hparams.data_ptr(),
+                                               self.sched.data_ptr(), lib.stream_ptr()))
 
     def set_hparams(self, lr: Optional[float] = None, grad_scale: float = 1.0) -> None:
-        """Advance the step counter and upload this step's hyper-parameters (call OUTSIDE a captured
-        graph, before replaying it)."""
+        """Host-side step advance: upload this step's hyper-parameters (call OUTSIDE a captured graph, before
+        replaying it).  Safe against host run-ahead (ring of event-guarded pinned buffers)."""
         self.t += 1
-        b1, b2 = self.betas
-        h = self._hp_host
-        h[0], h[1], h[2], h[3], h[4] = (self.lr if lr is None else lr), b1, b2, self.eps, self.weight_decay
-        h[5], h[6] = 1.0 - b1 ** self.t, 1.0 - b2 ** self.t
-        h[7] = self.max_grad_norm if self.max_grad_norm else 0.0
-        h[8] = grad_scale
-        self.hparams.copy_(h, non_blocking=True)
+        self._upload(self._static_hparams(self.lr if lr is None else lr, grad_scale))
+        if self._cuda:
+            self.step_dev.fill_(self.t)      # keep the device counter in step for a later advance()
 
     def launch(self) -> None:
         """Enqueue norm + update (graph-capturable; uses the hyper-parameters currently on the device)."""
@@ -138,6 +186,7 @@ class FusedAdamW:
             raise ValueError(f"FusedAdamW.load_state_dict: parameters at different step counts {sorted(steps)}: "
                              "the fused kernel applies one bias correction to the whole arena")
         self.t = steps.pop() if steps else 0
+        self.step_dev.fill_(self.t)
 
 
 def save_checkpoint(path: str, module: torch.nn.Module, optimizer: Optional["FusedAdamW"] = None, *, epoch: int = 0,
@@ -194,6 +243,7 @@ class FusionTrainStep:
                  contrastive: bool = True, allreduce: Optional[str] = "bf16"):
         self.model, self.head, self.arena = model, head, arena
         self.opt = FusedAdamW(arena, lr=lr, weight_decay=weight_decay, max_grad_norm=max_grad_norm)
+        self.opt.set_schedule(lr, total_steps)            # OneCycleLR evaluated on the device, per step
         self.max_lr, self.total_steps, self.contrastive, self.allreduce = lr, total_steps, contrastive, allreduce
         self.world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
 
@@ -213,5 +263,6 @@ class FusionTrainStep:
         loss = self.fwd_bwd(text, audio, video, targets)
         if self.world > 1:
             dp.allreduce_grads(self.arena, compress=None if self.allreduce == "fp32" else "bf16")
-        self.opt.step(lr=one_cycle_lr(self.opt.t, self.total_steps, self.max_lr))
+        self.opt.advance()
+        self.opt.launch()
         return loss

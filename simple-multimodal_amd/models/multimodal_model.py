@@ -155,9 +155,23 @@ def load_checkpoint_file(checkpoint_path: str) -> Dict:
     ``weights_only=True``, with this package's own ``config`` dataclasses as the only extra classes the unpickler
     may construct — the reference pickles its ``ExperimentConfig`` instance under the same module path
     (``config.ExperimentConfig``), which is why a bare ``weights_only=True`` refuses its files.
+    The reference's ``metrics`` entry holds sklearn results (advanced_trainer.py:245-261: ``f1_score`` /
+    ``accuracy_score`` return ``numpy.float64``), which pickle as ``numpy._core.multiarray.scalar`` + ``numpy.dtype``:
+    those reconstructors (data only, no code) and the float / int dtype classes are allowed too.
     A file that needs any other class is refused with torch's error."""
     import config as _cfg
+    import numpy as _np
     allow = [getattr(_cfg, n) for n in ("ModelConfig", "DataConfig", "ExperimentConfig") if hasattr(_cfg, n)]
+    allow.append(_np.dtype)
+    for modname in ("numpy._core.multiarray", "numpy.core.multiarray"):      # numpy >= 2 / numpy 1.x pickles
+        try:
+            mod = __import__(modname, fromlist=["scalar"])
+            # torch matches allowed globals by the (module, name) the pickle names: register under both spellings
+            allow.append((mod.scalar, f"{modname}.scalar"))
+        except (ImportError, AttributeError):
+            pass
+    for tname in ("float64", "float32", "int64", "int32", "bool_"):
+        allow.append(type(_np.dtype(getattr(_np, tname))))
     with torch.serialization.safe_globals(allow):
         ckpt = torch.load(checkpoint_path, map_location="cpu", weights_only=True)
     return ckpt if isinstance(ckpt, dict) and "model_state_dict" in ckpt else {"model_state_dict": ckpt}

@@ -71,3 +71,56 @@ def test_foreign_class_in_checkpoint_is_refused(tmp_path):
     torch.save({"model_state_dict": {}, "config": _NotAllowed()}, path)
     with pytest.raises(pickle.UnpicklingError):
         load_checkpoint_file(path)
+
+
+def test_numpy_scalar_metrics_load_and_other_classes_stay_refused(tmp_path):
+    """The reference stores sklearn metrics in ``metrics`` (advanced_trainer.py:245-261,400-407): f1_score /
+    accuracy_score return numpy.float64, pickled as numpy's scalar reconstructor + dtype.  The safe loader admits
+    exactly those (data, no code) and still refuses a file that needs any other class."""
+    import numpy as np
+    torch.manual_seed(0)
+    src = MultimodalEmotionModel(_cfg())
+    path = str(tmp_path / "best_model.pth")
+    torch.save({"epoch": 1, "model_state_dict": src.state_dict(), "optimizer_state_dict": {}, "scheduler_state_dict": {},
+                "metrics": {"val_f1_macro": np.float64(0.5), "val_f1_weighted": np.float64(0.25), "val_accuracy": np.float64(0.75),
+                            "n": np.int64(7)},
+                "config": cfgmod.ExperimentConfig()}, path)
+    ckpt = load_checkpoint_file(path)
+    assert float(ckpt["metrics"]["val_f1_macro"]) == 0.5 and int(ckpt["metrics"]["n"]) == 7
+    dst = load_pretrained_model(path, _cfg())
+    assert all(torch.equal(v, dst.state_dict()[k]) for k, v in src.state_dict().items())
+
+    import fractions
+    bad = str(tmp_path / "bad.pth")
+    torch.save({"model_state_dict": src.state_dict(), "metrics": {"f": fractions.Fraction(1, 2)}}, bad)
+    with pytest.raises(pickle.UnpicklingError):
+        load_checkpoint_file(bad)
+
+
+def test_pyg_23_gat_keys_are_remapped_on_load():
+    """torch-geometric 2.3 / 2.4 ``GATConv`` checkpoints carry ``lin_src.weight`` and ``lin_dst.weight`` (one shared
+    tensor under two names), >= 2.5 a single ``lin.weight``: both spellings load into the build's
+    ``gcn_layers.N.lin.weight`` and nothing else is tolerated as missing or unexpected."""
+    from models import fusion_layers as fl
+    cfg = _cfg()
+    torch.manual_seed(0)
+    src = fl.GraphFusion(cfg)
+    new_sd = src.state_dict()
+    old_sd = {}
+    for k, v in new_sd.items():
+        if k.endswith(".lin.weight"):
+            old_sd[k.replace(".lin.weight", ".lin_src.weight")] = v.clone()
+            old_sd[k.replace(".lin.weight", ".lin_dst.weight")] = v.clone()
+        else:
+            old_sd[k] = v.clone()
+    assert any("lin_src" in k for k in old_sd) and not any(k.endswith(".lin.weight") for k in old_sd)
+    torch.manual_seed(1)
+    dst = fl.GraphFusion(cfg)
+    res = dst.load_state_dict(old_sd, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    for k, v in new_sd.items():
+        assert torch.equal(v, dst.state_dict()[k]), k
+    with pytest.raises(RuntimeError):
+        bad = dict(old_sd)
+        bad["gcn_layers.0.lin_other.weight"] = torch.zeros(1)
+        fl.GraphFusion(cfg).load_state_dict(bad, strict=True)

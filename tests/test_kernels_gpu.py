@@ -658,3 +658,131 @@ def test_attention_generations_at_mult_shapes(impl, Tq, Tk):
     assert rel(q16.grad.view(B, Tq, d), qr.grad) < 2e-2
     assert rel(kv16.grad.view(B, Tk, 2 * d)[..., :d], kvr.grad[..., :d]) < 2e-2
     assert rel(kv16.grad.view(B, Tk, 2 * d)[..., d:], kvr.grad[..., d:]) < 2e-2
+
+
+# ---- round-2 additions: ADVICE r1 findings ---------------------------------------------------------------------
+def test_fused_adamw_device_schedule_many_steps_without_host_sync():
+    """the per-step hyper-parameters must not race with a host that runs ahead.  40 optimiser
+    steps are enqueued back to back with NO synchronisation — once through the device-side schedule (``advance()``:
+    step counter, bias corrections and OneCycle LR computed by a one-thread kernel) and once through the host-side
+    ``set_hparams`` (ring of event-guarded pinned buffers, longer than the ring) — against torch.optim.AdamW +
+    OneCycleLR + clip_grad_norm_ stepping on the CPU.  Early steps are where a late-read buffer would show: the
+    bias correction 1 - beta2^t changes 2x-3x per step there."""
+    from mmfusion import arena as arena_mod
+    from mmfusion.train import FusedAdamW, one_cycle_lr
+    steps, total, max_lr = 40, 50, 3e-3
+    for mode in ("device", "host"):
+        torch.manual_seed(0)
+        mod = torch.nn.Sequential(torch.nn.Linear(40, 72), torch.nn.Linear(72, 8)).cuda()
+        ref = torch.nn.Sequential(torch.nn.Linear(40, 72), torch.nn.Linear(72, 8))
+        ref.load_state_dict({k: v.cpu() for k, v in mod.state_dict().items()})
+        ar = arena_mod.ensure(mod)
+        opt = FusedAdamW(ar, lr=max_lr, weight_decay=1e-5, max_grad_norm=1.0)
+        opt.set_schedule(max_lr, total)
+        ropt = torch.optim.AdamW(ref.parameters(), lr=max_lr, weight_decay=1e-5)
+        rsch = torch.optim.lr_scheduler.OneCycleLR(ropt, max_lr=max_lr, total_steps=total, pct_start=0.1, anneal_strategy="cos")
+        gdev = [[(rnd(*p.shape, seed=1000 * s + i) * (0.2 + 3.0 * (s % 3))).to(DEV) for i, p in enumerate(mod.parameters())]
+                for s in range(steps)]
+        torch.cuda.synchronize()
+        for s in range(steps):                                  # enqueue only
+            for p, g in zip(mod.parameters(), gdev[s]):
+                p.grad.copy_(g, non_blocking=True)
+            if mode == "device":
+                opt.advance()
+            else:
+                opt.set_hparams(lr=one_cycle_lr(opt.t, total, max_lr))
+            opt.launch()
+        for s in range(steps):
+            for rp, g in zip(ref.parameters(), gdev[s]):
+                rp.grad = g.cpu()
+            torch.nn.utils.clip_grad_norm_(ref.parameters(), 1.0)
+            ropt.step()
+            rsch.step()
+        torch.cuda.synchronize()
+        assert opt.t == steps and int(opt.step_dev.item()) == steps
+        for p, rp in zip(mod.parameters(), ref.parameters()):
+            assert rel(p.detach(), rp.detach(), floor=1e-6) < 2e-5, mode
+        if mode == "device":
+            assert abs(float(opt.hparams[0]) - one_cycle_lr(steps - 1, total, max_lr)) < 1e-9 + 1e-6 * max_lr
+
+
+@pytest.mark.parametrize("lazy", [False, True])
+def test_linear_applied_twice_accumulates_both_uses(lazy):
+    """a weight used twice in one forward queues two deferred wgrad problems for ONE gradient
+    region; they must not share a grouped launch (non-atomic accumulate) nor run accumulate-before-overwrite under
+    lazy zeroing.  Three uses (the lazy race needs three), with and without a bias, against torch autograd."""
+    from mmfusion import arena as arena_mod
+    from mmfusion.ops import W
+    torch.manual_seed(0)
+    mod = torch.nn.ModuleDict({"a": torch.nn.Linear(128, 128), "b": torch.nn.Linear(128, 128, bias=False)}).cuda()
+    ar = arena_mod.ensure(mod)
+    x0 = bf(rnd(300, 128, seed=1))
+
+    def run_hip():
+        x = x0.clone().requires_grad_(True)
+        h = ops.linear(x, W(mod["a"].weight), W(mod["a"].bias))
+        h = ops.linear(h, W(mod["b"].weight))
+        h = ops.linear(h, W(mod["a"].weight), W(mod["a"].bias))
+        h = ops.linear(h, W(mod["b"].weight))
+        h = ops.linear(h, W(mod["a"].weight), W(mod["a"].bias))
+        (h.float() * 1e-2).sum().backward()
+        return x.grad
+    ar.zero_grad()
+    run_hip()                                   # teaches the arena its wgrad-managed regions
+    if lazy:
+        ar.grads.fill_(7.0)                     # stale values a lazy zero must not let through
+    ar.zero_grad(lazy=lazy)
+    gx = run_hip()
+    ar.finalize_grads()
+    torch.cuda.synchronize()
+    wa, ba, wb = (t.detach().to(torch.bfloat16).float().requires_grad_(True) for t in
+                  (mod["a"].weight, mod["a"].bias, mod["b"].weight))
+    ba = mod["a"].bias.detach().float().clone().requires_grad_(True)
+    x = x0.float().clone().requires_grad_(True)
+    r = lambda t: t.to(torch.bfloat16).float() + (t - t.detach())          # bf16 storage, straight-through
+    h = r(x @ wa.t() + ba)
+    h = r(h @ wb.t())
+    h = r(h @ wa.t() + ba)
+    h = r(h @ wb.t())
+    h = r(h @ wa.t() + ba)
+    (h * 1e-2).sum().backward()
+    assert rel(mod["a"].weight.grad, wa.grad) < 2e-2
+    assert rel(mod["b"].weight.grad, wb.grad) < 2e-2
+    assert rel(mod["a"].bias.grad, ba.grad) < 2e-2
+    assert rel(gx, x.grad) < 2e-2
+
+
+def test_contrastive_fusion_large_batch_branch_matches_small_batch_kernel():
+    """ContrastiveFusion with a per-rank batch above the fused InfoNCE kernel's limit (B > 64) takes the torch-op
+    branch (models/fusion_layers.py); both branches are the same arithmetic (reference :338-347, 361-375): checked
+    against the CPU oracle at B = 80, and the fused kernel against the torch branch at B = 64."""
+    import config as cfgmod
+    from models import fusion_layers as fl
+    from mmfusion import small_ops as sops
+    from oracle import ref_cpu
+    cfg = cfgmod.ModelConfig()
+    cfg.fusion_hidden_size, cfg.fusion_num_heads, cfg.fusion_dropout = 128, 2, 0.0
+    torch.manual_seed(4)
+    m = fl.ContrastiveFusion(cfg)
+    P = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    m = m.cuda().eval()
+    for B in (80, 64):
+        xs = [rnd(B, 128, seed=40 + i) for i in range(3)]
+        xr = [x.clone().requires_grad_(True) for x in xs]
+        ref = ref_cpu.contrastive_fusion(P, "", *xr, cfg.contrastive_temperature, compute_contrastive_loss=True)
+        (ref["fused_features"].sum() + sum(ref["contrastive_losses"].values())).backward()
+        xg = [x.cuda().requires_grad_(True) for x in xs]
+        assert (B > sops.NCE_MAX_B) == (B == 80)
+        out = m(*xg, compute_contrastive_loss=True)
+        (out["fused_features"].float().sum() + sum(out["contrastive_losses"].values())).backward()
+        torch.cuda.synchronize()
+        for k in ("text_audio", "text_video", "audio_video"):
+            want = float(ref["contrastive_losses"][k])
+            assert abs(float(out["contrastive_losses"][k]) - want) <= 1e-2 * max(1.0, abs(want)), (B, k)
+        for k in ("text_proj", "audio_proj", "video_proj", "fused_features"):
+            assert rel(out[k], ref[k]) < 1e-2, (B, k)
+        for g, r_ in zip(xg, xr):
+            l2 = float((g.grad.float().cpu() - r_.grad).norm() / r_.grad.norm())
+            assert l2 < 0.12, (B, l2)
+        for p in P.values():
+            p.grad = None

@@ -61,3 +61,19 @@ def test_split_wgrad_by_offset_partitions_by_arena_range(monkeypatch):
     # more parts than distinct regions: trailing parts are empty, bounds stay monotone
     parts3, bounds3 = ops.split_wgrad_by_offset([a], 3)
     assert [len(p) for p in parts3] == [1, 0, 0] and bounds3 == sorted(bounds3)
+
+
+def test_wgrad_rounds_separate_writers_of_one_region():
+    """A weight applied twice in one forward queues two wgrad problems for one gradient region; the grouped launch
+    accumulates non-atomically, so they must land in different launch rounds, in queue order."""
+    from mmfusion import ops
+    g1, g2, b1 = torch.empty(8, 4), torch.empty(8, 4), torch.empty(8)
+    dy, x = torch.empty(5, 8), torch.empty(5, 4)
+    a = (dy, x, g1, b1, None, True)          # first touch of g1 (overwrite)
+    b = (dy, x, g2, None, None, True)
+    c = (dy, x, g1, b1, None, False)         # second use of the same Linear
+    d = (dy, x, g1[2:6], None, None, False)  # a row block of the same region (overlap, different pointer)
+    e = (dy, x, torch.empty(3, 3), b1, None, False)   # other weight, same bias vector
+    rounds = ops._wgrad_rounds([a, b, c, d, e])
+    assert [len(r) for r in rounds] == [2, 1, 2]          # d and e touch disjoint memory: one round
+    assert rounds[0] == [a, b] and rounds[1] == [c] and rounds[2] == [d, e]
