@@ -307,6 +307,10 @@ int mmf_adaptive_combine_bwd(const float* hp, const float* W2, const float* atte
 /* The head-averaged (B, 3, 3) attention weights AdaptiveFusion returns (:432-434; MultiheadAttention averages its
  * weights over the heads): qkv bf16 [B*3][3 heads head_dim] packed q | k | v.  No gradient (inspection only). */
 int mmf_adaptive_attn_weights(const void* qkv_bf16, float* w, int B, int heads, int head_dim, void* stream);
+/* The head-averaged (B, T, T) self-attention weights the reference's audio / video encoder heads return
+ * (models/encoders.py:152-154,236-238): qkv bf16 [B*T][3 heads head_dim] packed q | k | v; T <= 2048, head_dim % 8 == 0.
+ * No gradient (inspection only). */
+int mmf_attn_weights_mean(const void* qkv_bf16, float* w, int B, int T, int heads, int head_dim, void* stream);
 /* Narrow linear heads, 1 <= N <= 16 outputs, f32 masters (LateFusion :50-60, EmotionClassifier / valence /
  * arousal / uncertainty heads models/multimodal_model.py:56-60,186-219): y = x W^T + b.  dx may be NULL. */
 int mmf_linear_narrow_fwd(const float* x, const float* W, const float* b, float* y, int M, int N, int K, void* stream);
@@ -333,13 +337,48 @@ int mmf_rowmask_apply(const float* x, const float* mask, float* y, int B, int d,
  * new values).
  * ------------------------------------------------------------------------------------------ */
 int mmf_sqnorm_f32(const float* x, int64_t n, float* out, void* stream);
-/* Device-side schedule (graph-capturable): *step += 1, then hparams[5], [6] = 1 - beta^step and, for sched[0] == 1,
- * hparams[0] = OneCycleLR(cos) learning rate of optimiser step (*step - 1) — torch.optim.lr_scheduler.OneCycleLR as
- * the reference configures it (training/advanced_trainer.py:102-110).  sched = {mode, max_lr, total_steps, pct_start,
- * div_factor, final_div_factor} as doubles on the device; mode 0 leaves hparams[0] alone. */
+/* Device-side schedule (graph-capturable): *step += 1, then — for sched[0] == 1 — hparams[0] = the OneCycleLR(cos)
+ * learning rate of optimiser step (*step - 1) and, for sched[6] != 0, hparams[1] = the cycled beta1 (OneCycleLR's
+ * cycle_momentum, on by default and therefore part of the reference recipe, training/advanced_trainer.py:102-110);
+ * finally hparams[5], [6] = 1 - beta^step from the current betas, as torch.optim.Adam forms them.
+ * sched = {mode, max_lr, total_steps, pct_start, div_factor, final_div_factor, cycle_momentum, base_momentum,
+ * max_momentum} as 9 doubles on the device; mode 0 leaves hparams[0], [1] alone. */
 int mmf_adamw_advance(int64_t* step, float* hparams, const double* sched, void* stream);
 int mmf_adamw_step(float* master, const float* grad, float* exp_avg, float* exp_avg_sq, void* shadow_bf16,
                    int64_t n, const float* hparams, const float* gnorm_sq, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Bidirectional LSTM layer recurrence (replaces the per-time-step loop of torch.nn.LSTM / MIOpen behind
+ * reference models/encoders.py:183-190,233: nn.LSTM(768, 384, num_layers=2, batch_first=True, bidirectional=True)).
+ * The input projections of all time steps are the caller's grouped GEMM (gx); this entry point runs the T sequential
+ * steps of both directions in ONE persistent launch with W_hh resident in registers (csrc/lstm.hip), and its backward
+ * produces the gate pre-activation gradients dgates that the caller feeds to the grouped dgrad / wgrad GEMMs.
+ * Time-major layout: row t*B + b.  Gate order i, f, g, o (torch).  Columns of the 2*4H-wide buffers:
+ * [direction 0 | direction 1] x [gate] x [H]; of the 2H-wide buffers: [direction 0 H | direction 1 H].
+ * y has a zero row block of B rows in front of time 0 and behind time T-1 (the caller zeroes them once): time t lives in
+ * row block t + 1.  B <= 64 per call; H (hidden size per direction) in {64, 128, 384}.
+ * workspace: >= mmf_bilstm_workspace_bytes() bytes of device memory, 4-byte aligned; zeroed by the call (stream-ordered);
+ * after the launch int32 word [2] is 0, or 1 if a workgroup gave up waiting for its peers (results then invalid).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct mmf_bilstm_args {
+  const void* gx;          /* fwd: f32 (T*B, 2*4H)  x_t W_ih^T, no bias                                        */
+  const void* w_hh[2];     /* bf16 (4H, H) per direction                                                      */
+  const float* b_ih[2];    /* fwd: f32 (4H)                                                                   */
+  const float* b_hh[2];    /* fwd: f32 (4H)                                                                   */
+  void* y;                 /* fwd out: bf16 ((T+2)*B, 2H), h_t of time t in row block t+1                      */
+  float* gates;            /* fwd out / bwd in: f32 (T*B, 2*4H) gate activations                               */
+  float* cell;             /* fwd out / bwd in: f32 (T*B, 2H) cell state c_t                                   */
+  const void* dy;          /* bwd in: bf16 (T*B, 2H) gradient of the layer output                              */
+  void* dgates;            /* bwd out: bf16 (T*B, 2*4H) gradient of the gate pre-activations                   */
+  int32_t T, B, H;
+} mmf_bilstm_args;
+size_t mmf_bilstm_workspace_bytes(void);
+int mmf_bilstm_layer_fwd(const mmf_bilstm_args* args, void* workspace, size_t workspace_bytes, void* stream);
+int mmf_bilstm_layer_bwd(const mmf_bilstm_args* args, void* workspace, size_t workspace_bytes, void* stream);
+
+/* out[(i1 * n0 + i0) * d + :] = in[(i0 * n1 + i1) * d + :]  — swaps the two leading axes of an (n0, n1, d) tensor
+ * ((B, T, d) <-> (T, B, d)); in_f32 selects an f32 source, the destination is bf16 unless out_f32. d % 8 == 0. */
+int mmf_swap01(const void* in, void* out, int n0, int n1, int d, int in_f32, int out_f32, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,346 @@
+// Bidirectional LSTM layer recurrence (reference models/encoders.py:183-190,233:
+// nn.LSTM(768, 384, num_layers=2, batch_first=True, bidirectional=True) over the 30 ViT frame features).
+//
+// The layer is split the MI355X way, not the cuDNN/MIOpen way (one GEMM launch per time step):
+//   * the input projections x_t W_ih^T of ALL time steps and both directions are one grouped MFMA GEMM launch
+//     (gemm2/gemm5, issued by the host side) -> gx (T*B, 2*4H) f32, time-major;
+//   * the recurrence — T strictly sequential steps of a (B x H) . (H x 4H) product plus the cell update — is ONE
+//     persistent launch: 2 * H/16 workgroups; a workgroup owns 16 hidden units of one direction, its four waves one
+//     gate each, and keeps its 64 x H slice of W_hh RESIDENT IN REGISTERS (H/32 MFMA A-fragments per lane) for all T
+//     steps.  Per step a wave runs H/32 v_mfma_f32_16x16x32_bf16 against h_{t-1} (B <= 64 rows as the B operand), the
+//     gates meet in LDS, each thread updates the cell state of its (unit, batch) pairs in registers and publishes
+//     h_t; the H/16 workgroups of a direction then meet at a device-scope counter barrier (release fence -> relaxed
+//     agent atomic add / relaxed poll -> acquire fence: MI355X_MICROARCH.md "valid forms"), because step t+1 of every
+//     workgroup needs all of h_t.  The workgroups of one direction are placed on ONE XCD (blockIdx % 8 = direction),
+//     so the exchanged h_t stays in that XCD's L2.  Every wait is BOUNDED: a workgroup that does not see its peers
+//     after ~2^22 polls sets status[0] and stops waiting, so the grid always drains.
+//   * backward (BPTT) mirrors it: per step the gate pre-activation gradients of the workgroup's 16 units, then
+//     dh_{t-1} = dG_t . W_hh restricted to its 16 columns (K = 4H split over the four waves, combined in LDS); dG
+//     (T*B, 2*4H) bf16 is the operand of the deferred wgrad GEMMs (dW_ih = dG^T x, dW_hh = dG^T h_prev, bias sums)
+//     and of the input-gradient GEMM, all on the grouped MFMA kernels.
+// Time-major layout inside: y is ((T+2)*B, 2H) bf16 with a zero row block in front and behind, so h_{t-1} of the first
+// step (either direction) is read from the padding and h_prev for the wgrad GEMM is a shifted VIEW of y.
+#include "mmf_internal.h"
+
+namespace {
+
+constexpr int LSTM_THREADS = 256;
+constexpr int LSTM_MAX_BT = 4;             // batch tiles of 16 rows: B <= 64 per launch
+constexpr int LSTM_SPIN_LIMIT = 1 << 22;
+
+struct LstmArgs {
+  mmf_bilstm_args p;
+  int* counters;                           // [0], [1]: arrivals per direction; [2]: status (0 ok, 1 a wait timed out)
+};
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) {
+  const float e = __expf(-2.f * fabsf(x));
+  const float t = (1.f - e) / (1.f + e);
+  return x < 0.f ? -t : t;
+}
+
+// All waves have stored what the peers will read; lane 0 publishes one arrival of this workgroup.
+__device__ __forceinline__ void grid_arrive(int* counter) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+// Wait until `target` arrivals are visible, then make the peers' stores visible to every wave of this workgroup.
+// Bounded: after LSTM_SPIN_LIMIT polls the workgroup gives up (status = 1) and never waits again (dead is sticky).
+__device__ __forceinline__ void grid_wait(int* counter, int target, int* status, int& dead) {
+  if (threadIdx.x == 0 && !dead) {
+    int it = 0;
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++it > LSTM_SPIN_LIMIT) { dead = 1; __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ bf16x8_t ld_frag(const unsigned short* p) {
+  return __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(p));
+}
+__device__ __forceinline__ bf16x8_t zero_frag() {
+  const u32x4_t z = {0u, 0u, 0u, 0u};
+  return __builtin_bit_cast(bf16x8_t, z);
+}
+
+// ---------------------------------------------------------------------------------------------- forward
+template <int H>
+__global__ __launch_bounds__(LSTM_THREADS)
+void bilstm_fwd_kernel(const LstmArgs a) {
+  constexpr int KS = H / 32;
+  const int dir = blockIdx.x & 7;
+  if (dir >= 2) return;                                      // only XCD 0 (forward) and XCD 1 (reverse) carry work
+  const int u0 = (blockIdx.x >> 3) * 16, nsl = H / 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, j = lane & 15;
+  const mmf_bilstm_args& P = a.p;
+  const int T = P.T, B = P.B, bt = (B + 15) >> 4;
+  __shared__ __attribute__((aligned(16))) float gs[4][LSTM_MAX_BT][64][4];
+
+  // resident A operand: rows (gate = wave) * H + u0 + j of W_hh, all of K
+  const unsigned short* Whh = static_cast<const unsigned short*>(P.w_hh[dir]);
+  bf16x8_t wf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) wf[ks] = ld_frag(Whh + (size_t)(wave * H + u0 + j) * H + 32 * ks + 8 * g);
+
+  // this thread's cells: unit u = 4 g + wave of the slice, batch rows b = 16 t + j
+  const int u = u0 + 4 * g + wave;
+  float bsum[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) bsum[q] = P.b_ih[dir][q * H + u] + P.b_hh[dir][q * H + u];
+  float c[LSTM_MAX_BT];
+#pragma unroll
+  for (int t = 0; t < LSTM_MAX_BT; ++t) c[t] = 0.f;
+
+  const float* gx = static_cast<const float*>(P.gx);
+  unsigned short* Y = static_cast<unsigned short*>(P.y);
+  int* counter = a.counters + dir;
+  int dead = 0;
+  __syncthreads();
+
+  for (int s = 0; s < T; ++s) {
+    const int time = dir ? T - 1 - s : s;
+    const int prev_blk = dir ? time + 2 : time;              // y row block of h_{t-1} (block time + 1 holds time)
+    float gxv[LSTM_MAX_BT][4];
+#pragma unroll
+    for (int t = 0; t < LSTM_MAX_BT; ++t) {
+      const int b = 16 * t + j;
+      if (t < bt && b < B) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) gxv[t][q] = gx[(size_t)(time * B + b) * (8 * H) + dir * 4 * H + q * H + u];
+      }
+    }
+    if (s > 0) grid_wait(counter, nsl * s, a.counters + 2, dead);
+    f32x4_t acc[LSTM_MAX_BT];
+#pragma unroll
+    for (int t = 0; t < LSTM_MAX_BT; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+      for (int t = 0; t < LSTM_MAX_BT; ++t) {
+        if (t < bt) {
+          const int b = 16 * t + j;
+          const bf16x8_t hf = b < B ? ld_frag(Y + (size_t)(prev_blk * B + b) * (2 * H) + dir * H + 32 * ks + 8 * g) : zero_frag();
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks], hf, acc[t], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < LSTM_MAX_BT; ++t)
+      if (t < bt) *reinterpret_cast<f32x4_t*>(&gs[wave][t][lane][0]) = acc[t];      // D[i = unit 4 g + e][j = batch]
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < LSTM_MAX_BT; ++t) {
+      const int b = 16 * t + j;
+      if (t < bt && b < B) {
+        const float ig = sigmoidf_(gs[0][t][lane][wave] + gxv[t][0] + bsum[0]);
+        const float fg = sigmoidf_(gs[1][t][lane][wave] + gxv[t][1] + bsum[1]);
+        const float gg = tanhf_(gs[2][t][lane][wave] + gxv[t][2] + bsum[2]);
+        const float og = sigmoidf_(gs[3][t][lane][wave] + gxv[t][3] + bsum[3]);
+        c[t] = fg * c[t] + ig * gg;
+        const float h = og * tanhf_(c[t]);
+        const size_t row = (size_t)(time * B + b);
+        Y[(size_t)((time + 1) * B + b) * (2 * H) + dir * H + u] = f32_to_bf16_bits(h);
+        float* ga = P.gates + row * (8 * H) + dir * 4 * H + u;
+        ga[0] = ig; ga[H] = fg; ga[2 * H] = gg; ga[3 * H] = og;
+        P.cell[row * (2 * H) + dir * H + u] = c[t];
+      }
+    }
+    if (s + 1 < T) grid_arrive(counter);                      // (its barrier also orders gs reads before the next writes)
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- backward
+template <int H>
+__global__ __launch_bounds__(LSTM_THREADS)
+void bilstm_bwd_kernel(const LstmArgs a) {
+  constexpr int KS = H / 32;                                  // K = 4H gate rows, wave w reduces rows [w H, (w+1) H)
+  const int dir = blockIdx.x & 7;
+  if (dir >= 2) return;
+  const int u0 = (blockIdx.x >> 3) * 16, nsl = H / 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, j = lane & 15;
+  const mmf_bilstm_args& P = a.p;
+  const int T = P.T, B = P.B, bt = (B + 15) >> 4;
+  __shared__ __attribute__((aligned(16))) float gs[4][LSTM_MAX_BT][64][4];
+
+  // resident A operand: A[i = unit u0 + j][k = gate row n] = W_hh[n][u0 + j], n = wave H + 32 ks + 8 g + e
+  const unsigned short* Whh = static_cast<const unsigned short*>(P.w_hh[dir]);
+  bf16x8_t wf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    s16x8_t v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (short)Whh[(size_t)(wave * H + 32 * ks + 8 * g + e) * H + u0 + j];
+    wf[ks] = __builtin_bit_cast(bf16x8_t, v);
+  }
+  const int u = u0 + 4 * g + wave;
+  float dc[LSTM_MAX_BT], dhr[LSTM_MAX_BT];
+#pragma unroll
+  for (int t = 0; t < LSTM_MAX_BT; ++t) { dc[t] = 0.f; dhr[t] = 0.f; }
+  const unsigned short* dY = static_cast<const unsigned short*>(P.dy);
+  unsigned short* dG = static_cast<unsigned short*>(P.dgates);
+  int* counter = a.counters + dir;
+  int dead = 0;
+
+  for (int s = T - 1; s >= 0; --s) {
+    const int time = dir ? T - 1 - s : s;
+    const int ptime = dir ? time + 1 : time - 1;              // the time step the forward ran before this one
+#pragma unroll
+    for (int t = 0; t < LSTM_MAX_BT; ++t) {
+      const int b = 16 * t + j;
+      if (t < bt && b < B) {
+        const size_t row = (size_t)(time * B + b);
+        const float* ga = P.gates + row * (8 * H) + dir * 4 * H + u;
+        const float ig = ga[0], fg = ga[H], gg = ga[2 * H], og = ga[3 * H];
+        const float ct = P.cell[row * (2 * H) + dir * H + u];
+        const float cp = s > 0 ? P.cell[(size_t)(ptime * B + b) * (2 * H) + dir * H + u] : 0.f;
+        const float dh = bf16_bits_to_f32(dY[row * (2 * H) + dir * H + u]) + dhr[t];
+        const float tc = tanhf_(ct);
+        const float dct = dc[t] + dh * og * (1.f - tc * tc);
+        const float d_i = dct * gg * ig * (1.f - ig);
+        const float d_f = dct * cp * fg * (1.f - fg);
+        const float d_g = dct * ig * (1.f - gg * gg);
+        const float d_o = dh * tc * og * (1.f - og);
+        dc[t] = dct * fg;
+        unsigned short* dg = dG + row * (8 * H) + dir * 4 * H + u;
+        dg[0] = f32_to_bf16_bits(d_i); dg[H] = f32_to_bf16_bits(d_f);
+        dg[2 * H] = f32_to_bf16_bits(d_g); dg[3 * H] = f32_to_bf16_bits(d_o);
+      }
+    }
+    if (s == 0) break;
+    grid_arrive(counter);
+    grid_wait(counter, nsl * (T - s), a.counters + 2, dead);
+    // dh_{prev}[unit][batch] = sum_n W_hh[n][unit] dG_t[batch][n]
+    f32x4_t acc[LSTM_MAX_BT];
+#pragma unroll
+    for (int t = 0; t < LSTM_MAX_BT; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+      for (int t = 0; t < LSTM_MAX_BT; ++t) {
+        if (t < bt) {
+          const int b = 16 * t + j;
+          const bf16x8_t df = b < B ? ld_frag(dG + (size_t)(time * B + b) * (8 * H) + dir * 4 * H + wave * H + 32 * ks + 8 * g)
+                                    : zero_frag();
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks], df, acc[t], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < LSTM_MAX_BT; ++t)
+      if (t < bt) *reinterpret_cast<f32x4_t*>(&gs[wave][t][lane][0]) = acc[t];
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < LSTM_MAX_BT; ++t)
+      if (t < bt) dhr[t] = gs[0][t][lane][wave] + gs[1][t][lane][wave] + gs[2][t][lane][wave] + gs[3][t][lane][wave];
+    __syncthreads();                                          // gs is rewritten by the next step's products
+  }
+}
+
+// (n0, n1, d) -> (n1, n0, d) with optional dtype change; one 16-byte (8-element) chunk of the output per thread
+template <bool IN_F32, bool OUT_F32>
+__global__ __launch_bounds__(256)
+void swap01_kernel(const void* __restrict__ in, void* __restrict__ out, int n0, int n1, int d) {
+  const int cpr = d >> 3;
+  const int64_t total = (int64_t)n0 * n1 * cpr;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int ch = (int)(i % cpr);
+    const int64_t orow = i / cpr;                      // i1 * n0 + i0
+    const int i0 = (int)(orow % n0), i1 = (int)(orow / n0);
+    const int64_t src = ((int64_t)i0 * n1 + i1) * d + ch * 8, dst = orow * d + ch * 8;
+    float v[8];
+    if (IN_F32) {
+      const f32x4_t a = *reinterpret_cast<const f32x4_t*>(static_cast<const float*>(in) + src);
+      const f32x4_t b = *reinterpret_cast<const f32x4_t*>(static_cast<const float*>(in) + src + 4);
+      v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+    } else {
+      const u32x4_t x = *reinterpret_cast<const u32x4_t*>(static_cast<const unsigned short*>(in) + src);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[2 * e] = bf16lo(x[e]); v[2 * e + 1] = bf16hi(x[e]); }
+    }
+    if (OUT_F32) {
+      *reinterpret_cast<f32x4_t*>(static_cast<float*>(out) + dst) = f32x4_t{v[0], v[1], v[2], v[3]};
+      *reinterpret_cast<f32x4_t*>(static_cast<float*>(out) + dst + 4) = f32x4_t{v[4], v[5], v[6], v[7]};
+    } else {
+      const u32x4_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+      *reinterpret_cast<u32x4_t*>(static_cast<unsigned short*>(out) + dst) = o;
+    }
+  }
+}
+
+int check_lstm(const char* who, const mmf_bilstm_args* p, void* ws, size_t ws_bytes, bool bwd) {
+  if (!p) MMF_FAIL(MMF_E_SHAPE, "%s: null argument block", who);
+  if (p->T <= 0 || p->B <= 0 || p->B > 16 * LSTM_MAX_BT) MMF_FAIL(MMF_E_SHAPE, "%s: T=%d B=%d (B <= %d per launch)", who, p->T, p->B, 16 * LSTM_MAX_BT);
+  if (p->H != 384 && p->H != 128 && p->H != 64) MMF_FAIL(MMF_E_UNSUPPORTED, "%s: hidden size per direction %d (built: 64, 128, 384)", who, p->H);
+  if (!ws || ws_bytes < mmf_bilstm_workspace_bytes() || (reinterpret_cast<uintptr_t>(ws) & 3)) MMF_FAIL(MMF_E_SHAPE, "%s: workspace", who);
+  for (int d = 0; d < 2; ++d)
+    if (!p->w_hh[d] || !mmf_aligned16(p->w_hh[d])) MMF_FAIL(MMF_E_ALIGN, "%s: w_hh[%d] null or unaligned", who, d);
+  if (!p->gates || !p->cell) MMF_FAIL(MMF_E_SHAPE, "%s: gates / cell buffers", who);
+  if (!bwd) {
+    if (!p->gx || !p->y || !mmf_aligned16(p->y)) MMF_FAIL(MMF_E_SHAPE, "%s: gx / y", who);
+    for (int d = 0; d < 2; ++d) if (!p->b_ih[d] || !p->b_hh[d]) MMF_FAIL(MMF_E_SHAPE, "%s: biases", who);
+  } else {
+    if (!p->dy || !p->dgates || !mmf_aligned16(p->dgates)) MMF_FAIL(MMF_E_SHAPE, "%s: dy / dgates", who);
+  }
+  return MMF_OK;
+}
+
+template <typename K>
+void launch_lstm(K kernel, const LstmArgs& a, int H, hipStream_t s) {
+  hipLaunchKernelGGL(kernel, dim3(8 * (H / 16)), dim3(LSTM_THREADS), 0, s, a);
+}
+
+}  // namespace
+
+extern "C" size_t mmf_bilstm_workspace_bytes(void) { return 64; }
+
+extern "C" int mmf_bilstm_layer_fwd(const mmf_bilstm_args* args, void* workspace, size_t workspace_bytes, void* stream) {
+  if (int rc = check_lstm("mmf_bilstm_layer_fwd", args, workspace, workspace_bytes, false)) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (hipMemsetAsync(workspace, 0, 64, s) != hipSuccess) MMF_FAIL(MMF_E_LAUNCH, "mmf_bilstm_layer_fwd: workspace memset failed");
+  LstmArgs a; a.p = *args; a.counters = static_cast<int*>(workspace);
+  switch (args->H) {
+    case 384: launch_lstm(bilstm_fwd_kernel<384>, a, 384, s); break;
+    case 128: launch_lstm(bilstm_fwd_kernel<128>, a, 128, s); break;
+    default:  launch_lstm(bilstm_fwd_kernel<64>, a, 64, s); break;
+  }
+  MMF_CHECK_LAUNCH("mmf_bilstm_layer_fwd");
+  return MMF_OK;
+}
+
+extern "C" int mmf_bilstm_layer_bwd(const mmf_bilstm_args* args, void* workspace, size_t workspace_bytes, void* stream) {
+  if (int rc = check_lstm("mmf_bilstm_layer_bwd", args, workspace, workspace_bytes, true)) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (hipMemsetAsync(workspace, 0, 64, s) != hipSuccess) MMF_FAIL(MMF_E_LAUNCH, "mmf_bilstm_layer_bwd: workspace memset failed");
+  LstmArgs a; a.p = *args; a.counters = static_cast<int*>(workspace);
+  switch (args->H) {
+    case 384: launch_lstm(bilstm_bwd_kernel<384>, a, 384, s); break;
+    case 128: launch_lstm(bilstm_bwd_kernel<128>, a, 128, s); break;
+    default:  launch_lstm(bilstm_bwd_kernel<64>, a, 64, s); break;
+  }
+  MMF_CHECK_LAUNCH("mmf_bilstm_layer_bwd");
+  return MMF_OK;
+}
+
+extern "C" int mmf_swap01(const void* in, void* out, int n0, int n1, int d, int in_f32, int out_f32, void* stream) {
+  if (!in || !out || n0 <= 0 || n1 <= 0 || d <= 0 || (d & 7)) MMF_FAIL(MMF_E_SHAPE, "mmf_swap01: n0=%d n1=%d d=%d (d %% 8 == 0)", n0, n1, d);
+  if (!mmf_aligned16(in) || !mmf_aligned16(out)) MMF_FAIL(MMF_E_ALIGN, "mmf_swap01: unaligned pointer");
+  const int64_t total = (int64_t)n0 * n1 * (d >> 3);
+  const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (in_f32 && out_f32)       hipLaunchKernelGGL((swap01_kernel<true, true>), dim3(grid), dim3(256), 0, s, in, out, n0, n1, d);
+  else if (in_f32)             hipLaunchKernelGGL((swap01_kernel<true, false>), dim3(grid), dim3(256), 0, s, in, out, n0, n1, d);
+  else if (out_f32)            hipLaunchKernelGGL((swap01_kernel<false, true>), dim3(grid), dim3(256), 0, s, in, out, n0, n1, d);
+  else                         hipLaunchKernelGGL((swap01_kernel<false, false>), dim3(grid), dim3(256), 0, s, in, out, n0, n1, d);
+  MMF_CHECK_LAUNCH("mmf_swap01");
+  return MMF_OK;
+}

@@ -76,35 +76,39 @@ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __r
 }
 
 // Device-resident step counter + schedule: ONE thread advances the optimiser's step count and derives this step's
-// learning rate and bias corrections into the hyper-parameter array the update kernel reads, so nothing about a
-// step's hyper-parameters crosses the PCIe bus and a captured training step replays with the right values however
+// learning rate, beta1 and bias corrections into the hyper-parameter array the update kernel reads, so nothing about
+// a step's hyper-parameters crosses the PCIe bus and a captured training step replays with the right values however
 // far the host runs ahead (a pinned host buffer rewritten per step is read when the GPU executes the copy, not when
 // the host enqueues it).  sched: [0] mode (0 = constant hp[0], 1 = OneCycleLR cos, three_phase = False)
-// [1] max_lr [2] total_steps [3] pct_start [4] div_factor [5] final_div_factor   (reference recipe
-// training/advanced_trainer.py:102-110).  Arithmetic in double like torch.optim.lr_scheduler.OneCycleLR.
+// [1] max_lr [2] total_steps [3] pct_start [4] div_factor [5] final_div_factor [6] cycle_momentum (0 / 1)
+// [7] base_momentum [8] max_momentum   (reference recipe training/advanced_trainer.py:102-110: OneCycleLR with its
+// defaults, i.e. cycle_momentum=True — Adam's beta1 runs 0.95 -> 0.85 -> 0.95 against the learning rate, and
+// torch.optim.Adam forms its bias correction from the CURRENT beta1: 1 - beta1(t)^t).  Arithmetic in double like
+// torch.optim.lr_scheduler.OneCycleLR.
 __global__ void adamw_advance_kernel(long long* __restrict__ step, float* __restrict__ hp,
                                      const double* __restrict__ sched) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const long long t = *step + 1;                 // number of the optimiser step about to run, 1-based
   *step = t;
-  const double b1 = hp[1], b2 = hp[2];
-  hp[5] = (float)(1.0 - pow(b1, (double)t));
-  hp[6] = (float)(1.0 - pow(b2, (double)t));
+  double b1 = hp[1];
+  const double b2 = hp[2];
   if (sched[0] == 1.0) {
     const double max_lr = sched[1], total = sched[2], pct = sched[3];
     const double initial = max_lr / sched[4], minimum = initial / sched[5];
     const double up_end = pct * total - 1.0, down_end = total - 1.0, s = (double)(t - 1);
     const double kPi = 3.14159265358979323846;
-    double lr;
-    if (s <= up_end || up_end >= down_end) {
-      const double q = up_end > 0.0 ? s / up_end : 1.0;
-      lr = max_lr + (initial - max_lr) / 2.0 * (cos(kPi * q) + 1.0);
-    } else {
-      const double q = fmin(1.0, (s - up_end) / (down_end - up_end));
-      lr = minimum + (max_lr - minimum) / 2.0 * (cos(kPi * q) + 1.0);
+    const bool up = s <= up_end || up_end >= down_end;
+    const double q = up ? (up_end > 0.0 ? s / up_end : 1.0) : fmin(1.0, (s - up_end) / (down_end - up_end));
+    const double w = (cos(kPi * q) + 1.0) / 2.0;                     // anneal(start, end) = end + (start - end) w
+    hp[0] = (float)(up ? max_lr + (initial - max_lr) * w : minimum + (max_lr - minimum) * w);
+    if (sched[6] != 0.0) {
+      const double base_m = sched[7], max_m = sched[8];
+      b1 = up ? base_m + (max_m - base_m) * w : max_m + (base_m - max_m) * w;
+      hp[1] = (float)b1;
     }
-    hp[0] = (float)lr;
   }
+  hp[5] = (float)(1.0 - pow(b1, (double)t));
+  hp[6] = (float)(1.0 - pow(b2, (double)t));
 }
 
 inline int opt_grid(int64_t n) {

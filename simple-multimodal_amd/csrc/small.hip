@@ -476,6 +476,68 @@ void ada_attn_weights_kernel(const unsigned short* __restrict__ qkv, float* __re
   }
 }
 
+// Head-averaged attention weights of a self-attention over T tokens, w[b][i][j] = mean_h softmax_j(q_i.k_j / sqrt(dh)):
+// what nn.MultiheadAttention returns beside its output and the reference's audio / video encoders pass on
+// (models/encoders.py:152-154,236-238).  qkv: bf16 rows [B*T][3 d] packed q | k | v.  One workgroup per (query i, b);
+// a thread owns keys j = tid, tid + 256, ... (T <= 256 * AWM_MAXK); fp32 dot products straight from the bf16 rows
+// (the row of q sits in LDS).  No gradient: inspection output, like the (B, 3, 3) weights above.
+constexpr int AWM_MAXK = 8;
+__global__ __launch_bounds__(SM_THREADS)
+void attn_weights_mean_kernel(const unsigned short* __restrict__ qkv, float* __restrict__ w, int T, int H, int dh, float scale) {
+  extern __shared__ float awm_q[];                       // d floats
+  __shared__ float red[SM_WAVES];
+  const int i = blockIdx.x, b = blockIdx.y, d = H * dh, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned short* qrow = qkv + ((size_t)b * T + i) * 3 * d;
+  for (int c = tid; c < d; c += SM_THREADS) awm_q[c] = bf16_bits_to_f32(qrow[c]) * scale;
+  __syncthreads();
+  float outv[AWM_MAXK];
+#pragma unroll
+  for (int k = 0; k < AWM_MAXK; ++k) outv[k] = 0.f;
+  for (int h = 0; h < H; ++h) {
+    float sc[AWM_MAXK], mx = -3.0e38f;
+#pragma unroll
+    for (int k = 0; k < AWM_MAXK; ++k) {
+      const int j = tid + SM_THREADS * k;
+      sc[k] = -3.0e38f;
+      if (j < T) {
+        const unsigned short* kr = qkv + ((size_t)b * T + j) * 3 * d + d + h * dh;
+        float s = 0.f;
+        for (int c = 0; c < dh; c += 8) {
+          const u32x4_t x = *reinterpret_cast<const u32x4_t*>(kr + c);
+          const float* qq = awm_q + h * dh + c;
+          s += bf16lo(x[0]) * qq[0] + bf16hi(x[0]) * qq[1] + bf16lo(x[1]) * qq[2] + bf16hi(x[1]) * qq[3] +
+               bf16lo(x[2]) * qq[4] + bf16hi(x[2]) * qq[5] + bf16lo(x[3]) * qq[6] + bf16hi(x[3]) * qq[7];
+        }
+        sc[k] = s;
+        mx = fmaxf(mx, s);
+      }
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < AWM_MAXK; ++k) {
+      sc[k] = (tid + SM_THREADS * k < T) ? __expf(sc[k] - mx) : 0.f;
+      sum += sc[k];
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) red[wave] = sum;
+    __syncthreads();
+    const float inv = 1.f / ((red[0] + red[1] + red[2] + red[3]) * (float)H);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < AWM_MAXK; ++k) outv[k] += sc[k] * inv;
+  }
+#pragma unroll
+  for (int k = 0; k < AWM_MAXK; ++k) {
+    const int j = tid + SM_THREADS * k;
+    if (j < T) w[((size_t)b * T + i) * T + j] = outv[k];
+  }
+}
+
 // ================================================================================================
 // Narrow linear heads, N <= 16 outputs (LateFusion's three d -> 7 classifiers :50-60, EmotionClassifier's last
 // layer and the valence / arousal / uncertainty heads, models/multimodal_model.py:56-60,186-219), f32 in / f32
@@ -738,6 +800,18 @@ extern "C" int mmf_rowmask_apply(const float* x, const float* mask, float* y, in
   const int grid = (int)((n + SM_THREADS - 1) / SM_THREADS < 2048 ? (n + SM_THREADS - 1) / SM_THREADS : 2048);
   hipLaunchKernelGGL(rowmask_kernel, dim3(grid), dim3(SM_THREADS), 0, static_cast<hipStream_t>(stream), x, mask, y, B, d);
   MMF_CHECK_LAUNCH("mmf_rowmask_apply");
+  return MMF_OK;
+}
+
+extern "C" int mmf_attn_weights_mean(const void* qkv_bf16, float* w, int B, int T, int heads, int head_dim, void* stream) {
+  if (!qkv_bf16 || !w || B <= 0 || T <= 0 || T > SM_THREADS * AWM_MAXK || heads <= 0 || head_dim <= 0 || (head_dim & 7) ||
+      B > 65535 || heads * head_dim * 4 > 48 * 1024 || !mmf_aligned16(qkv_bf16))
+    MMF_FAIL(MMF_E_SHAPE, "mmf_attn_weights_mean: B=%d T=%d (<= %d) heads=%d head_dim=%d (multiple of 8)", B, T,
+             SM_THREADS * AWM_MAXK, heads, head_dim);
+  hipLaunchKernelGGL(attn_weights_mean_kernel, dim3(T, B), dim3(SM_THREADS), (size_t)heads * head_dim * 4,
+                     static_cast<hipStream_t>(stream), static_cast<const unsigned short*>(qkv_bf16), w, T, heads, head_dim,
+                     1.f / sqrtf((float)head_dim));
+  MMF_CHECK_LAUNCH("mmf_attn_weights_mean");
   return MMF_OK;
 }
 

@@ -30,6 +30,7 @@ SYMBOLS = (
     "mmf_gat3_dense_fwd", "mmf_gat3_dense_bwd", "mmf_infonce_fwd", "mmf_infonce_bwd", "mmf_adaptive_combine_fwd",
     "mmf_adaptive_combine_bwd", "mmf_adaptive_attn_weights", "mmf_linear_narrow_fwd", "mmf_linear_narrow_bwd", "mmf_stack3_embed_fwd",
     "mmf_stack3_embed_bwd", "mmf_rowmask_apply", "mmf_zero_ranges_f32",
+    "mmf_attn_weights_mean", "mmf_bilstm_workspace_bytes", "mmf_bilstm_layer_fwd", "mmf_bilstm_layer_bwd", "mmf_swap01",
 )
 
 
@@ -77,6 +78,12 @@ POOL_MAX = 4
 class Gat3Params(C.Structure):
     _fields_ = [("B", C.c_int32), ("heads", C.c_int32), ("C", C.c_int32), ("relu", C.c_int32),
                 ("negative_slope", C.c_float), ("dropout_p", C.c_float), ("rng_state", C.c_void_p), ("site", C.c_uint32)]
+
+
+class BiLstmArgs(C.Structure):
+    _fields_ = [("gx", C.c_void_p), ("w_hh", C.c_void_p * 2), ("b_ih", C.c_void_p * 2), ("b_hh", C.c_void_p * 2),
+                ("y", C.c_void_p), ("gates", C.c_void_p), ("cell", C.c_void_p), ("dy", C.c_void_p), ("dgates", C.c_void_p),
+                ("T", C.c_int32), ("B", C.c_int32), ("H", C.c_int32)]
 
 
 class ColsumProblem(C.Structure):
@@ -139,6 +146,7 @@ def load() -> C.CDLL:
     lib.mmf_adaptive_combine_fwd.argtypes = [vp] * 6 + [i32, i32, vp]
     lib.mmf_adaptive_combine_bwd.argtypes = [vp] * 10 + [i32, i32, vp]
     lib.mmf_adaptive_attn_weights.argtypes = [vp, vp, i32, i32, i32, vp]
+    lib.mmf_attn_weights_mean.argtypes = [vp, vp, i32, i32, i32, i32, vp]
     lib.mmf_linear_narrow_fwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp]
     lib.mmf_linear_narrow_bwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]
     lib.mmf_stack3_embed_fwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp]
@@ -147,6 +155,10 @@ def load() -> C.CDLL:
     lib.mmf_zero_ranges_f32.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), i32, vp]
     lib.mmf_adamw_step.argtypes = [vp, vp, vp, vp, vp, i64, vp, vp, vp]
     lib.mmf_adamw_advance.argtypes = [vp, vp, vp, vp]
+    lib.mmf_bilstm_workspace_bytes.restype = C.c_size_t
+    lib.mmf_bilstm_layer_fwd.argtypes = [C.POINTER(BiLstmArgs), vp, C.c_size_t, vp]
+    lib.mmf_bilstm_layer_bwd.argtypes = [C.POINTER(BiLstmArgs), vp, C.c_size_t, vp]
+    lib.mmf_swap01.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
     for name in SYMBOLS:
         getattr(lib, name)          # AttributeError here = header and .so disagree
     if lib.mmf_version() != 1:

@@ -7,7 +7,8 @@ Reproduces the recipe of the reference's ``AdvancedTrainer`` for the part of the
                          contrastive losses (+ 0.1 * aux, + 0.5 * distillation when present);
   * optimiser (:85-94)   AdamW, weight_decay 1e-5; the reference's 0.1x LR group only holds HF-backbone
                          parameters, which are outside this build, so all fusion parameters use ``lr``;
-  * schedule (:102-110)  OneCycleLR(max_lr, pct_start=0.1, cos);
+  * schedule (:102-110)  OneCycleLR(max_lr, pct_start=0.1, cos) with torch's defaults, i.e. INCLUDING
+                         ``cycle_momentum``: Adam's beta1 runs 0.95 -> 0.85 -> 0.95 against the learning rate;
   * clipping (:174,179)  ``clip_grad_norm_(1.0)``;
   * no per-step ``.item()`` syncs (the reference does four, :185-188).
 
@@ -28,17 +29,26 @@ from . import dp, lib
 from .arena import ParamArena
 
 
-def one_cycle_lr(step: int, total_steps: int, max_lr: float, pct_start: float = 0.1,
-                 div_factor: float = 25.0, final_div_factor: float = 1e4) -> float:
-    """torch.optim.lr_scheduler.OneCycleLR (anneal_strategy='cos', three_phase=False): LR to use for
-    optimiser step number ``step`` (0-based: step 0 uses initial_lr = max_lr / div_factor)."""
+def one_cycle(step: int, total_steps: int, max_lr: float, pct_start: float = 0.1, div_factor: float = 25.0,
+              final_div_factor: float = 1e4, base_momentum: float = 0.85, max_momentum: float = 0.95):
+    """torch.optim.lr_scheduler.OneCycleLR (anneal_strategy='cos', three_phase=False, cycle_momentum=True — the
+    defaults the reference runs with, advanced_trainer.py:102-110): (learning rate, Adam beta1) to use for optimiser
+    step number ``step`` (0-based: step 0 uses initial_lr = max_lr / div_factor and beta1 = max_momentum)."""
     initial, minimum = max_lr / div_factor, max_lr / div_factor / final_div_factor
     up_end = float(pct_start * total_steps) - 1.0
     down_end = float(total_steps) - 1.0
-    cos = lambda a, b, pct: b + (a - b) / 2.0 * (math.cos(math.pi * pct) + 1.0)
+    anneal = lambda a, b, pct: b + (a - b) / 2.0 * (math.cos(math.pi * pct) + 1.0)
     if step <= up_end or up_end >= down_end:
-        return cos(initial, max_lr, step / up_end if up_end > 0 else 1.0)
-    return cos(max_lr, minimum, min(1.0, (step - up_end) / (down_end - up_end)))
+        pct = step / up_end if up_end > 0 else 1.0
+        return anneal(initial, max_lr, pct), anneal(max_momentum, base_momentum, pct)
+    pct = min(1.0, (step - up_end) / (down_end - up_end))
+    return anneal(max_lr, minimum, pct), anneal(base_momentum, max_momentum, pct)
+
+
+def one_cycle_lr(step: int, total_steps: int, max_lr: float, pct_start: float = 0.1,
+                 div_factor: float = 25.0, final_div_factor: float = 1e4) -> float:
+    """The learning-rate half of ``one_cycle``."""
+    return one_cycle(step, total_steps, max_lr, pct_start, div_factor, final_div_factor)[0]
 
 
 class FusedAdamW:
@@ -67,7 +77,7 @@ class FusedAdamW:
         self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
         self.hparams = torch.zeros(9, dtype=torch.float32, device=dev)
         self.step_dev = torch.zeros(1, dtype=torch.int64, device=dev)
-        self.sched = torch.zeros(6, dtype=torch.float64, device=dev)
+        self.sched = torch.zeros(9, dtype=torch.float64, device=dev)
         self._cuda = dev.type == "cuda"
         self._ring = [torch.zeros(9, dtype=torch.float32).pin_memory() if self._cuda else torch.zeros(9)
                       for _ in range(self._RING)]
@@ -76,8 +86,9 @@ class FusedAdamW:
         self.t = 0
         self._upload(self._static_hparams(lr, 1.0))
 
-    def _static_hparams(self, lr: float, grad_scale: float):
+    def _static_hparams(self, lr: float, grad_scale: float, beta1: Optional[float] = None):
         b1, b2 = self.betas
+        b1 = b1 if beta1 is None else beta1
         return [lr, b1, b2, self.eps, self.weight_decay, 1.0 - b1 ** max(self.t, 1), 1.0 - b2 ** max(self.t, 1),
                 self.max_grad_norm if self.max_grad_norm else 0.0, grad_scale]
 
@@ -97,10 +108,13 @@ class FusedAdamW:
             self._ring_events[i] = ev
 
     def set_schedule(self, max_lr: float, total_steps: int, pct_start: float = 0.1, div_factor: float = 25.0,
-                     final_div_factor: float = 1e4) -> None:
-        """OneCycleLR(cos) evaluated on the device by ``advance()`` (reference advanced_trainer.py:102-110)."""
-        self.sched.copy_(torch.tensor([1.0, max_lr, float(total_steps), pct_start, div_factor, final_div_factor],
-                                      dtype=torch.float64))
+                     final_div_factor: float = 1e4, cycle_momentum: bool = True, base_momentum: float = 0.85,
+                     max_momentum: float = 0.95) -> None:
+        """OneCycleLR(cos) evaluated on the device by ``advance()``.  Defaults are torch's, which the reference
+        runs with (advanced_trainer.py:102-110): that includes ``cycle_momentum=True`` — Adam's beta1 is cycled
+        0.95 -> 0.85 -> 0.95 against the learning rate."""
+        self.sched.copy_(torch.tensor([1.0, max_lr, float(total_steps), pct_start, div_factor, final_div_factor,
+                                       1.0 if cycle_momentum else 0.0, base_momentum, max_momentum], dtype=torch.float64))
 
     def advance(self) -> None:
         """Device-side step advance (graph-capturable): counter += 1, bias corrections, scheduled LR."""
@@ -108,11 +122,12 @@ class FusedAdamW:
         lib.check(lib.load().mmf_adamw_advance(self.step_dev.data_ptr(), self.hparams.data_ptr(),
                                                self.sched.data_ptr(), lib.stream_ptr()))
 
-    def set_hparams(self, lr: Optional[float] = None, grad_scale: float = 1.0) -> None:
+    def set_hparams(self, lr: Optional[float] = None, grad_scale: float = 1.0, beta1: Optional[float] = None) -> None:
         """Host-side step advance: upload this step's hyper-parameters (call OUTSIDE a captured graph, before
-        replaying it).  Safe against host run-ahead (ring of event-guarded pinned buffers)."""
+        replaying it).  Safe against host run-ahead (ring of event-guarded pinned buffers).  ``beta1``: this step's
+        Adam beta1 when the schedule cycles it (``one_cycle``); the bias correction uses it, as torch's Adam does."""
         self.t += 1
-        self._upload(self._static_hparams(self.lr if lr is None else lr, grad_scale))
+        self._upload(self._static_hparams(self.lr if lr is None else lr, grad_scale, beta1))
         if self._cuda:
             self.step_dev.fill_(self.t)      # keep the device counter in step for a later advance()
 
@@ -129,8 +144,8 @@ class FusedAdamW:
                                    self.hparams.data_ptr(), gn, st))
         a.mark_shadow_fresh()
 
-    def step(self, lr: Optional[float] = None, grad_scale: float = 1.0) -> None:
-        self.set_hparams(lr, grad_scale)
+    def step(self, lr: Optional[float] = None, grad_scale: float = 1.0, beta1: Optional[float] = None) -> None:
+        self.set_hparams(lr, grad_scale, beta1)
         self.launch()
 
     # -- checkpoint interchange ------------------------------------------------------------------

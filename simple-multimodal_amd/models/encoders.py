@@ -14,7 +14,11 @@ therefore take a ``backbone`` argument:
   * ``config.feature_inputs = True`` (dynamic attribute) builds no backbone at all: the ``forward``
     inputs are then precomputed backbone features ``(B, T, hidden)`` — the synthetic-feature route
     of BASELINE.json's configs.
-The video BiLSTM (reference :183-190) stays on ``torch.nn.LSTM``.
+The video BiLSTM (reference :183-190,233) runs on the HIP path too (``mmfusion.lstm_ops``: grouped MFMA GEMMs for the
+input projections, one persistent launch per layer for the 30 sequential steps of both directions); the
+``torch.nn.LSTM`` module is only the parameter container (state_dict keys ``temporal_lstm.weight_ih_l0`` ...).
+The audio / video heads return the head-averaged ``attention_weights`` (B, T, T) like the reference
+(:152-154,236-238; no gradient); ``config.encoder_attention_weights = False`` (dynamic attribute) skips that kernel.
 """
 from __future__ import annotations
 
@@ -61,19 +65,25 @@ class AdapterLayer(_FusionBase):
         return ops.to_f32(y).reshape(x.shape)
 
 
-def _mha_mean_project(mha: _MHAParams, projection: nn.Linear, seq: torch.Tensor, p: float = 0.0
-                      ) -> Tuple[torch.Tensor, torch.Tensor]:
+def _mha_mean_project(mha: _MHAParams, projection: nn.Linear, seq: torch.Tensor, p: float = 0.0,
+                      want_weights: bool = True) -> Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]:
     """self-MHA over T -> mean(T) -> Linear  (reference :152-160 / :236-244).
-    Returns (projected (B, d_fusion) fp32, attended (B, T, hidden) fp32)."""
+    Returns (projected (B, d_fusion) fp32, attended (B, T, hidden) fp32, head-averaged weights (B, T, T) fp32 | None)."""
     B, T, hdim = seq.shape
     rows = _as_rows(seq)
     qkv = ops.linear(rows, mha.qkv_spec().w, mha.qkv_spec().b)
+    weights = None
+    if want_weights and T <= 2048 and mha.head_dim % 8 == 0:
+        from mmfusion import lib as _lib
+        weights = torch.empty((B, T, T), dtype=torch.float32, device=qkv.device)
+        _lib.check(_lib.load().mmf_attn_weights_mean(qkv.data_ptr(), weights.data_ptr(), B, T, mha.num_heads, mha.head_dim,
+                                                     _lib.stream_ptr()))
     att = ops.attention_group([AttnSpec(B, T, T, q=(0, 0), k=(0, hdim), v=(0, 2 * hdim))],
                               mha.num_heads, mha.head_dim, [qkv], dropout_p=p)[0]
     attended = ops.linear(att, *_wb(mha.out_proj))
     pooled = ops.meanpool_cat([attended.view(B, T, hdim)])
     projected = ops.dropout(ops.linear(pooled, *_wb(projection), out_f32=True), p, True)     # reference :161 / :245
-    return projected, ops.to_f32(attended).view(B, T, hdim)
+    return projected, ops.to_f32(attended).view(B, T, hdim), weights
 
 
 class TextEncoder(_FusionBase):
@@ -138,9 +148,10 @@ class AudioEncoder(_FusionBase):
         seq = waveform if self.model is None else self.model(waveform).last_hidden_state
         if use_adapter and self.adapter is not None:
             seq = self.adapter(seq)
-        projected, attended = _mha_mean_project(self.temporal_attention, self.projection, seq,
-                                                _p(self, self.config.fusion_dropout))
-        return {"features": projected, "sequence_output": attended, "attention_weights": None}
+        projected, attended, weights = _mha_mean_project(self.temporal_attention, self.projection, seq,
+                                                         _p(self, self.config.fusion_dropout),
+                                                         getattr(self.config, "encoder_attention_weights", True))
+        return {"features": projected, "sequence_output": attended, "attention_weights": weights}
 
 
 class VideoEncoder(_FusionBase):
@@ -168,10 +179,12 @@ class VideoEncoder(_FusionBase):
             frame_features = cls.view(B, n, -1)
         if use_adapter and self.adapter is not None:
             frame_features = self.adapter(frame_features)
-        lstm_out, _ = self.temporal_lstm(frame_features.float())
-        projected, attended = _mha_mean_project(self.facial_attention, self.projection, lstm_out,
-                                                _p(self, self.config.fusion_dropout))
-        return {"features": projected, "sequence_output": attended, "attention_weights": None}
+        from mmfusion import lstm_ops
+        lstm_out = lstm_ops.bilstm(self.temporal_lstm, frame_features, _p(self, self.config.fusion_dropout))   # :233
+        projected, attended, weights = _mha_mean_project(self.facial_attention, self.projection, lstm_out,
+                                                         _p(self, self.config.fusion_dropout),
+                                                         getattr(self.config, "encoder_attention_weights", True))
+        return {"features": projected, "sequence_output": attended, "attention_weights": weights}
 
 
 class ModalityDropout(nn.Module):

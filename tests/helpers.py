@@ -68,14 +68,17 @@ def run_oracle(meta, P, inputs):
     raise KeyError(c)
 
 
-def oracle_fwd_bwd(meta, P=None, inputs=None):
-    """Run the oracle forward + probe-loss backward; returns (flat outputs, input grads, param grads)."""
+def oracle_fwd_bwd(meta, P=None, inputs=None, storage="fp32"):
+    """Run the oracle forward + probe-loss backward; returns (flat outputs, input grads, param grads).
+    storage="bf16": the oracle rounds at the HIP path's bf16 storage points (ref_cpu.bf16_storage)."""
+    import contextlib
     P = P if P is not None else fixture_params(meta)
     inputs = inputs if inputs is not None else fixture_inputs(meta)
     Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
     xin = [t.clone().requires_grad_(True) for t in inputs]
-    out = run_oracle(meta, Pg, xin)
-    synth.probe_loss(out).backward()
+    with (ref_cpu.bf16_storage() if storage == "bf16" else contextlib.nullcontext()):
+        out = run_oracle(meta, Pg, xin)
+        synth.probe_loss(out).backward()
     flat = {k: v.detach() for k, v in synth.flatten_outputs(out).items()}
     gp = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in Pg.items()}
     return flat, [t.grad for t in xin], gp

@@ -666,10 +666,11 @@ def test_fused_adamw_device_schedule_many_steps_without_host_sync():
     steps are enqueued back to back with NO synchronisation — once through the device-side schedule (``advance()``:
     step counter, bias corrections and OneCycle LR computed by a one-thread kernel) and once through the host-side
     ``set_hparams`` (ring of event-guarded pinned buffers, longer than the ring) — against torch.optim.AdamW +
-    OneCycleLR + clip_grad_norm_ stepping on the CPU.  Early steps are where a late-read buffer would show: the
-    bias correction 1 - beta2^t changes 2x-3x per step there."""
+    OneCycleLR (torch's defaults, as the reference: beta1 is cycled with the learning rate) + clip_grad_norm_
+    stepping on the CPU.  Early steps are where a late-read buffer would show: the bias correction 1 - beta2^t
+    changes 2x-3x per step there."""
     from mmfusion import arena as arena_mod
-    from mmfusion.train import FusedAdamW, one_cycle_lr
+    from mmfusion.train import FusedAdamW, one_cycle, one_cycle_lr
     steps, total, max_lr = 40, 50, 3e-3
     for mode in ("device", "host"):
         torch.manual_seed(0)
@@ -690,7 +691,8 @@ def test_fused_adamw_device_schedule_many_steps_without_host_sync():
             if mode == "device":
                 opt.advance()
             else:
-                opt.set_hparams(lr=one_cycle_lr(opt.t, total, max_lr))
+                lr_s, b1_s = one_cycle(opt.t, total, max_lr)
+                opt.set_hparams(lr=lr_s, beta1=b1_s)
             opt.launch()
         for s in range(steps):
             for rp, g in zip(ref.parameters(), gdev[s]):
@@ -739,7 +741,7 @@ def test_linear_applied_twice_accumulates_both_uses(lazy):
                   (mod["a"].weight, mod["a"].bias, mod["b"].weight))
     ba = mod["a"].bias.detach().float().clone().requires_grad_(True)
     x = x0.float().clone().requires_grad_(True)
-    r = lambda t: t.to(torch.bfloat16).float() + (t - t.detach())          # bf16 storage, straight-through
+    r = lambda t: t.to(torch.bfloat16).float()          # bf16 storage (the cast's autograd is the identity)
     h = r(x @ wa.t() + ba)
     h = r(h @ wb.t())
     h = r(h @ wa.t() + ba)

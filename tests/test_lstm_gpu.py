@@ -1,0 +1,104 @@
+"""GPU parity of the HIP bidirectional LSTM (reference models/encoders.py:183-190,233) against
+``torch.nn.LSTM`` in fp32 on the CPU — the reference's own arithmetic for this piece — forward and backward (input
+gradient and every weight / bias gradient of both layers and both directions), and of the head-averaged encoder
+attention weights (reference :152-154,236-238).  bf16 storage / f32 accumulate: outputs within 1e-2 * max(1, |ref|max),
+gradients by relative L2."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from helpers import l2_rel  # noqa: E402
+from mmfusion import arena as arena_mod, lstm_ops  # noqa: E402
+
+
+def _pair(In, H, layers, seed=0):
+    torch.manual_seed(seed)
+    ref = torch.nn.LSTM(In, H, num_layers=layers, batch_first=True, bidirectional=True)
+    hip = torch.nn.LSTM(In, H, num_layers=layers, batch_first=True, bidirectional=True)
+    hip.load_state_dict(ref.state_dict())
+    hip = hip.cuda()
+    arena_mod.ensure(hip)
+    return ref, hip
+
+
+@pytest.mark.parametrize("B,T,In,H,layers", [(5, 7, 40, 64, 2), (16, 30, 768, 384, 2), (70, 4, 64, 64, 1), (3, 1, 128, 128, 2)])
+def test_bilstm_matches_torch_lstm_fp32(B, T, In, H, layers):
+    """(16, 30, 768, 384, 2) is the reference's video temporal head at B = 16; B = 70 exercises the batch chunking
+    (64 + 6), T = 1 the no-recurrence edge, B = 5 / 3 the partial batch tile."""
+    ref, hip = _pair(In, H, layers)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(B, T, In, generator=g)
+    w = torch.randn(B, T, 2 * H, generator=g)
+    xr = x.clone().requires_grad_(True)
+    yr, _ = ref(xr)
+    (yr * w).sum().backward()
+
+    xg = x.cuda().requires_grad_(True)
+    arena = arena_mod.ensure(hip)
+    arena.zero_grad()
+    y = lstm_ops.bilstm(hip, xg)
+    assert y.shape == (B, T, 2 * H) and y.dtype == torch.bfloat16
+    (y.float() * w.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    err = float((y.float().cpu() - yr.detach()).abs().max())
+    assert err <= 1e-2 * max(1.0, float(yr.abs().max())), f"output abs err {err:.3e}"
+    assert l2_rel(y.float(), yr) <= 1e-2, f"output rel L2 {l2_rel(y.float(), yr):.3e}"
+    assert l2_rel(xg.grad, xr.grad) <= 3e-2, f"input grad rel L2 {l2_rel(xg.grad, xr.grad):.3e}"
+    for (n, p), (_, q) in zip(hip.named_parameters(), ref.named_parameters()):
+        e = l2_rel(p.grad, q.grad)
+        assert e <= 3e-2, f"grad {n} rel L2 {e:.3e}"
+
+
+def test_bilstm_is_deterministic_and_reports_a_clean_status():
+    ref, hip = _pair(64, 64, 2, seed=3)
+    x = torch.randn(9, 12, 64, generator=torch.Generator().manual_seed(2)).cuda()
+    a = lstm_ops.bilstm(hip, x)
+    b = lstm_ops.bilstm(hip, x)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    # the status word of a direct layer launch: 0 = every grid barrier was met
+    h = lstm_ops.swap01(x).view(12 * 9, 64)
+    params = []
+    for suffix in ("", "_reverse"):
+        params += [getattr(hip, f"{n}_l0{suffix}") for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+    y = lstm_ops._BiLSTMLayer.apply(h, 12, 9, *params)
+    assert lstm_ops.last_status(y.grad_fn.status) == 0
+
+
+def test_swap01_round_trip_and_dtypes():
+    x = torch.randn(5, 7, 48, generator=torch.Generator().manual_seed(0)).cuda().requires_grad_(True)
+    y = lstm_ops.swap01(x)
+    assert y.shape == (7, 5, 48) and y.dtype == torch.bfloat16
+    assert torch.equal(y, x.detach().transpose(0, 1).contiguous().to(torch.bfloat16))
+    y32 = lstm_ops.swap01(x.detach().to(torch.bfloat16), out_f32=True)
+    assert torch.equal(y32, x.detach().to(torch.bfloat16).float().transpose(0, 1).contiguous())
+    g = torch.randn(7, 5, 48, generator=torch.Generator().manual_seed(1)).cuda().to(torch.bfloat16)
+    y.backward(g)
+    assert x.grad.dtype == torch.float32 and torch.equal(x.grad, g.float().transpose(0, 1).contiguous())
+
+
+@pytest.mark.parametrize("T", [30, 499, 3])
+def test_encoder_heads_return_head_averaged_attention_weights(T):
+    """reference encoders.py:152-154,236-238 return nn.MultiheadAttention's head-averaged weights (B, T, T)."""
+    import config as cfgmod
+    from models.encoders import AudioEncoder
+    from oracle import ref_cpu
+    cfg = cfgmod.ModelConfig()
+    cfg.feature_inputs = True
+    cfg.fusion_hidden_size, cfg.fusion_dropout = 256, 0.0
+    torch.manual_seed(2)
+    enc = AudioEncoder(cfg)
+    seq = torch.randn(4, T, 768, generator=torch.Generator().manual_seed(5))
+    P = {k: v.detach().float().clone() for k, v in enc.state_dict().items()}
+    _, want = ref_cpu.mha(P, "temporal_attention.", seq, seq, 8)
+    enc = enc.cuda().eval()
+    with torch.no_grad():
+        out = enc(seq.cuda())
+    got = out["attention_weights"]
+    assert got.shape == (4, T, T)
+    assert float((got.sum(-1) - 1).abs().max()) < 1e-4
+    assert float((got.cpu() - want).abs().max()) <= 1e-2 * max(1.0, float(want.max())) * 0.2       # 2e-3: bf16 q, k
+    cfg.encoder_attention_weights = False
+    with torch.no_grad():
+        assert enc(seq.cuda())["attention_weights"] is None

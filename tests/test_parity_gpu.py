@@ -20,6 +20,12 @@ GIN_L2, GIN_MAX = 1.2e-1, 2.5e-1   # input gradients: relative L2 error, and max
 GP_L2 = 1.5e-1                     # parameter gradients: relative L2 error ...
 GP_L2_RELU = 3.5e-1                # ... except weights/biases that feed a ReLU directly (see below)
 GP_NORM = 1.5e-1                   # every parameter gradient's norm vs the reference fixture
+# Against the oracle in bf16-storage mode (oracle/ref_cpu.py: it rounds where the HIP path stores bf16 and models the
+# attention kernels' online softmax), the ReLU masks coincide and what is left is fp32 summation order plus the rare
+# rounding-boundary flip.  Measured on MI355X (profiles/parity_r02.txt): input gradients <= 1.2e-2, parameters <= 1.5e-2.
+OUT_BF16 = 5e-3                    # forward outputs: max |hip - oracle_bf16| / max|oracle_bf16| (one bf16 ulp of the largest value)
+GIN_L2_BF16 = 2e-2                 # input gradients, relative L2
+GP_L2_BF16 = 2e-2                  # every parameter gradient, relative L2 (ReLU-fed ones included)
 # Measured on MI355X (tools/parity_report.py, profiles/parity_r01.txt): input-grad L2 1-8e-2, parameter
 # L2 0.2-10e-2 (ReLU-fed up to 15e-2), norm ratios 0.99-1.03 except 3-element / near-cancelling tensors.
 # A structural error (transpose, missing term, double accumulation) shows up as an error of O(1).
@@ -81,6 +87,16 @@ def test_module_parity(name):
         assert l2_rel(gp[k], ref) <= tol, f"{name}: param grad {k} L2 {l2_rel(gp[k], ref):.3e} > {tol}"
     for k, (norm, dot) in meta["grad_checks"].items():
         assert abs(float(gp[k].norm()) - norm) <= GP_NORM * max(norm, 1e-6), f"{name}: grad norm {k}"
+    # the tight check: the same arithmetic with bf16 storage
+    b_out, b_gin, b_gp = oracle_fwd_bwd(meta, storage="bf16")
+    for k in b_out:
+        assert rel_err(out[k], b_out[k]) <= OUT_BF16 * 2, f"{name}: output {k} vs bf16-storage oracle {rel_err(out[k], b_out[k]):.3e}"
+    for i, ref in enumerate(b_gin):
+        assert l2_rel(gin[i], ref) <= GIN_L2_BF16, f"{name}: input grad {i} vs bf16-storage oracle L2 {l2_rel(gin[i], ref):.3e}"
+    for k, ref in b_gp.items():
+        if float(ref.abs().max()) == 0.0:
+            continue
+        assert l2_rel(gp[k], ref) <= GP_L2_BF16, f"{name}: param grad {k} vs bf16-storage oracle L2 {l2_rel(gp[k], ref):.3e}"
 
 
 def test_mult_at_the_bench_configuration_matches_oracle():

@@ -1,7 +1,7 @@
 """CPU: host logic of the training-step harness (schedule, loss composition)."""
 import torch
 
-from mmfusion.train import fusion_loss, one_cycle_lr
+from mmfusion.train import fusion_loss, one_cycle, one_cycle_lr
 
 
 def test_one_cycle_matches_torch():
@@ -15,6 +15,26 @@ def test_one_cycle_matches_torch():
         opt.step()
         if step + 1 < total:
             sch.step()
+
+
+def test_one_cycle_momentum_matches_torch_adam():
+    """OneCycleLR's defaults (what the reference runs with, advanced_trainer.py:102-110) cycle Adam's beta1 between
+    0.95 and 0.85 against the learning rate; ``one_cycle`` must reproduce both series."""
+    total, max_lr = 40, 1e-3
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.AdamW([p], lr=max_lr)
+    sch = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=max_lr, total_steps=total, pct_start=0.1, anneal_strategy="cos")
+    seen = []
+    for step in range(total):
+        lr, b1 = one_cycle(step, total, max_lr)
+        assert abs(opt.param_groups[0]["lr"] - lr) < 1e-12 + 1e-9 * max_lr, step
+        assert abs(opt.param_groups[0]["betas"][0] - b1) < 1e-12, step
+        assert opt.param_groups[0]["betas"][1] == 0.999
+        seen.append(b1)
+        opt.step()
+        if step + 1 < total:
+            sch.step()
+    assert seen[0] == 0.95 and abs(min(seen) - 0.85) < 1e-12 and abs(seen[-1] - 0.95) < 1e-9
 
 
 def test_fusion_loss_recipe():

@@ -18,8 +18,9 @@ def main():
     for name in (sys.argv[1:] or sorted(CASES)):
         fx = load_fixture(name)
         out, gin, gp = run_hip(fx.meta)
-        o_out, o_gin, o_gp = oracle_fwd_bwd(fx.meta)
-        print(f"== {name}")
+        storage = os.environ.get("ORACLE_STORAGE", "fp32")      # bf16: the oracle rounds at the HIP path's storage points
+        o_out, o_gin, o_gp = oracle_fwd_bwd(fx.meta, storage=storage)
+        print(f"== {name} (oracle storage {storage})")
         for k in sorted(out):
             print(f"   out  {k:45s} abs {float((out[k] - o_out[k]).abs().max()):.3e} rel {rel_err(out[k], o_out[k]):.3e}")
         for i, g in enumerate(gin):
