@@ -229,6 +229,10 @@ typedef struct mmf_add3_problem {
   int64_t n;
 } mmf_add3_problem;
 int mmf_add3_grouped(const mmf_add3_problem* problems, int num_problems, void* stream);
+/* y = x_0 + ... + x_{n-1} (2 <= n <= MMF_ADDN_MAX bf16 tensors of numel elements, f32 accumulate, bf16 or f32 out) in
+ * one pass: the gradient of a tensor the forward used n times (MulT's input rows: models/fusion_layers.py:146-158). */
+#define MMF_ADDN_MAX 8
+int mmf_addn_bf16(const void* const* xs, int n, void* y, int64_t numel, int out_f32, void* stream);
 /* y[b][j] = mean_t x[b][t][j]  (models/fusion_layers.py:166-168); x bf16 [B][T][d], y bf16 with
  * row stride ldy (lets the three pooled modalities land side by side = torch.cat, :171). */
 int mmf_meanpool_fwd(const void* x, void* y, int B, int T, int d, int ldy, void* stream);
@@ -346,6 +350,28 @@ int mmf_sqnorm_f32(const float* x, int64_t n, float* out, void* stream);
 int mmf_adamw_advance(int64_t* step, float* hparams, const double* sched, void* stream);
 int mmf_adamw_step(float* master, const float* grad, float* exp_avg, float* exp_avg_sq, void* shadow_bf16,
                    int64_t n, const float* hparams, const float* gnorm_sq, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * fp32-storage parity mode (BASELINE.json north_star: "within 1e-3 fp32").  Every operand f32 in HBM, the exact f32
+ * MFMA (v_mfma_f32_32x32x2_f32: a k-ordered fp32 fmaf chain) instead of bf16 MFMA.  Same problem struct, layouts
+ * and epilogue contract as mmf_gemm_grouped (A, B, C, aux are f32 here; MMF_EPI_DROPOUT is not available).
+ * mmf_gemm_f32_batched runs ONE problem over an nb0 x nb1 batch: operand X of batch (i0, i1) starts at
+ * X + i0 * strideX[0] + i1 * strideX[1] (elements) — the per-(batch, head) products of the explicit-scores attention
+ * the reference computes (torch F.multi_head_attention_forward, need_weights path): S = Q K^T, softmax rows,
+ * O = P V, and their backward products.  mmf_softmax_rows_f32: S <- softmax(scale * S) per row, in place;
+ * mmf_softmax_bwd_rows_f32: dP <- scale * P * (dP - rowsum(dP * P)), in place.  mmf_layernorm_f32_*: nn.LayerNorm
+ * with f32 rows (dgamma / dbeta are accumulated into with atomics).
+ * ------------------------------------------------------------------------------------------ */
+int mmf_gemm_f32_grouped(const mmf_gemm_problem* problems, int num_problems, int layout, int epilogue, float alpha,
+                         void* stream);
+int mmf_gemm_f32_batched(const mmf_gemm_problem* problem, int layout, int epilogue, float alpha, int nb0, int nb1,
+                         const int64_t strideA[2], const int64_t strideB[2], const int64_t strideC[2], void* stream);
+int mmf_softmax_rows_f32(float* S, int64_t rows, int cols, float scale, void* stream);
+int mmf_softmax_bwd_rows_f32(const float* P, float* dP, int64_t rows, int cols, float scale, void* stream);
+int mmf_layernorm_f32_fwd(const float* x, float* y, const float* gamma, const float* beta, float* mean, float* rstd,
+                          int rows, int d, float eps, void* stream);
+int mmf_layernorm_f32_bwd(const float* x, const float* dy, const float* gamma, const float* mean, const float* rstd,
+                          float* dx, float* dgamma, float* dbeta, int rows, int d, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Bidirectional LSTM layer recurrence (replaces the per-time-step loop of torch.nn.LSTM / MIOpen behind

@@ -424,6 +424,63 @@ extern "C" int mmf_add3_grouped(const mmf_add3_problem* problems, int num_proble
   return MMF_OK;
 }
 
+// y = sum of n (2..MMF_ADDN_MAX) bf16 tensors, f32 accumulate, ONE pass: the gradient of a tensor used n times in
+// the forward (MulT's input rows feed two q-projections, two k/v-projections, two residuals and the three-way sum,
+// reference models/fusion_layers.py:146-158) instead of n - 1 pairwise adds.
+struct AddNArgs { int n; const unsigned short* x[MMF_ADDN_MAX]; };
+template <bool OUT_F32>
+__global__ __launch_bounds__(EW_THREADS)
+void addn_kernel(const AddNArgs a, void* __restrict__ y, int64_t numel) {
+  const int64_t nvec = numel >> 3;
+  const int64_t stride = (int64_t)gridDim.x * EW_THREADS;
+  for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < nvec; i += stride) {
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int k = 0; k < MMF_ADDN_MAX; ++k) {
+      if (k < a.n) {
+        const u32x4_t v = *reinterpret_cast<const u32x4_t*>(a.x[k] + i * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { acc[2 * e] += bf16lo(v[e]); acc[2 * e + 1] += bf16hi(v[e]); }
+      }
+    }
+    if (OUT_F32) {
+      float* o = static_cast<float*>(y) + i * 8;
+      *reinterpret_cast<f32x4_t*>(o) = f32x4_t{acc[0], acc[1], acc[2], acc[3]};
+      *reinterpret_cast<f32x4_t*>(o + 4) = f32x4_t{acc[4], acc[5], acc[6], acc[7]};
+    } else {
+      const u32x4_t o = {pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3]), pack_bf16x2(acc[4], acc[5]), pack_bf16x2(acc[6], acc[7])};
+      *reinterpret_cast<u32x4_t*>(static_cast<unsigned short*>(y) + i * 8) = o;
+    }
+  }
+  if (blockIdx.x == 0) {
+    const int64_t t = (nvec << 3) + threadIdx.x;
+    if (t < numel) {
+      float s = 0.f;
+      for (int k = 0; k < a.n; ++k) s += bf16_bits_to_f32(a.x[k][t]);
+      if (OUT_F32) static_cast<float*>(y)[t] = s; else static_cast<unsigned short*>(y)[t] = f32_to_bf16_bits(s);
+    }
+  }
+}
+
+extern "C" int mmf_addn_bf16(const void* const* xs, int n, void* y, int64_t numel, int out_f32, void* stream) {
+  if (!xs || n < 2 || n > MMF_ADDN_MAX || !y || numel <= 0) MMF_FAIL(MMF_E_SHAPE, "mmf_addn_bf16: n=%d (2..%d) numel=%lld", n, MMF_ADDN_MAX, (long long)numel);
+  AddNArgs a; a.n = n;
+  for (int k = 0; k < MMF_ADDN_MAX; ++k) a.x[k] = nullptr;
+  for (int k = 0; k < n; ++k) {
+    EW_PTR_CHECK("mmf_addn_bf16", xs[k] && mmf_aligned16(xs[k]));
+    a.x[k] = static_cast<const unsigned short*>(xs[k]);
+  }
+  EW_PTR_CHECK("mmf_addn_bf16", mmf_aligned16(y));
+  const int grid = ew_grid(numel >> 3);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (out_f32) hipLaunchKernelGGL(addn_kernel<true>, dim3(grid), dim3(EW_THREADS), 0, s, a, y, numel);
+  else         hipLaunchKernelGGL(addn_kernel<false>, dim3(grid), dim3(EW_THREADS), 0, s, a, y, numel);
+  MMF_CHECK_LAUNCH("mmf_addn_bf16");
+  return MMF_OK;
+}
+
 extern "C" int mmf_dropout(const void* x, void* y, int64_t n, int is_f32, float p, const uint64_t* rng_state,
                            uint32_t site, void* stream) {
   if (n <= 0) return MMF_OK;

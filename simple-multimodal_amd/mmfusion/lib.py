@@ -24,13 +24,14 @@ SYMBOLS = (
     "mmf_version", "mmf_last_error", "mmf_device_cu_count", "mmf_gemm_grouped", "mmf_gemm_grouped_ex", "mmf_gemm_select_impl", "mmf_gemm_last_impl",
     "mmf_attn_fwd_grouped_ex", "mmf_attn_bwd_grouped_ex", "mmf_dropout", "mmf_attn_select_impl",
     "mmf_attn_fwd_grouped", "mmf_attn_bwd_grouped", "mmf_layernorm_fwd_grouped",
-    "mmf_layernorm_bwd_grouped", "mmf_layernorm_bwd_workspace_bytes", "mmf_cast_f32_to_bf16", "mmf_cast_bf16_to_f32", "mmf_cast_bf16_to_f32_scaled", "mmf_cast_f32_to_bf16_2d", "mmf_add3_bf16", "mmf_add3_grouped",
+    "mmf_layernorm_bwd_grouped", "mmf_layernorm_bwd_workspace_bytes", "mmf_cast_f32_to_bf16", "mmf_cast_bf16_to_f32", "mmf_cast_bf16_to_f32_scaled", "mmf_cast_f32_to_bf16_2d", "mmf_add3_bf16", "mmf_add3_grouped", "mmf_addn_bf16",
     "mmf_meanpool_fwd", "mmf_meanpool_bwd", "mmf_meanpool_cat_fwd", "mmf_meanpool_cat_bwd", "mmf_colsum_bf16", "mmf_colsum_grouped", "mmf_relu_bwd_bf16", "mmf_relu_bwd_mixed",
     "mmf_sqnorm_f32", "mmf_adamw_step", "mmf_adamw_advance", "mmf_skinny_linear_fwd", "mmf_skinny_linear_dgrad",
     "mmf_gat3_dense_fwd", "mmf_gat3_dense_bwd", "mmf_infonce_fwd", "mmf_infonce_bwd", "mmf_adaptive_combine_fwd",
     "mmf_adaptive_combine_bwd", "mmf_adaptive_attn_weights", "mmf_linear_narrow_fwd", "mmf_linear_narrow_bwd", "mmf_stack3_embed_fwd",
     "mmf_stack3_embed_bwd", "mmf_rowmask_apply", "mmf_zero_ranges_f32",
-    "mmf_attn_weights_mean", "mmf_bilstm_workspace_bytes", "mmf_bilstm_layer_fwd", "mmf_bilstm_layer_bwd", "mmf_swap01",
+    "mmf_attn_weights_mean", "mmf_gemm_f32_grouped", "mmf_gemm_f32_batched", "mmf_softmax_rows_f32", "mmf_softmax_bwd_rows_f32",
+    "mmf_layernorm_f32_fwd", "mmf_layernorm_f32_bwd", "mmf_bilstm_workspace_bytes", "mmf_bilstm_layer_fwd", "mmf_bilstm_layer_bwd", "mmf_swap01",
 )
 
 
@@ -66,6 +67,7 @@ class SkinnyProblem(C.Structure):
 
 SKINNY_MAX_M, SKINNY_MAX_PROBLEMS = 64, 24
 ADD3_MAX = 8
+ADDN_MAX = 8
 
 
 class Add3Problem(C.Structure):
@@ -127,6 +129,7 @@ def load() -> C.CDLL:
     lib.mmf_cast_f32_to_bf16_2d.argtypes = [vp, vp, i32, i32, i32, vp]
     lib.mmf_add3_bf16.argtypes = [vp, vp, vp, vp, i64, vp]
     lib.mmf_add3_grouped.argtypes = [C.POINTER(Add3Problem), i32, vp]
+    lib.mmf_addn_bf16.argtypes = [C.POINTER(C.c_void_p), i32, vp, i64, i32, vp]
     lib.mmf_meanpool_fwd.argtypes = [vp, vp, i32, i32, i32, i32, vp]
     lib.mmf_meanpool_bwd.argtypes = [vp, vp, i32, i32, i32, i32, vp]
     lib.mmf_meanpool_cat_fwd.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_int), i32, vp, i32, i32, i32, vp]
@@ -159,6 +162,13 @@ def load() -> C.CDLL:
     lib.mmf_bilstm_layer_fwd.argtypes = [C.POINTER(BiLstmArgs), vp, C.c_size_t, vp]
     lib.mmf_bilstm_layer_bwd.argtypes = [C.POINTER(BiLstmArgs), vp, C.c_size_t, vp]
     lib.mmf_swap01.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
+    S2 = C.c_int64 * 2
+    lib.mmf_gemm_f32_grouped.argtypes = [C.POINTER(GemmProblem), i32, i32, i32, f32, vp]
+    lib.mmf_gemm_f32_batched.argtypes = [C.POINTER(GemmProblem), i32, i32, f32, i32, i32, S2, S2, S2, vp]
+    lib.mmf_softmax_rows_f32.argtypes = [vp, i64, i32, f32, vp]
+    lib.mmf_softmax_bwd_rows_f32.argtypes = [vp, vp, i64, i32, f32, vp]
+    lib.mmf_layernorm_f32_fwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, f32, vp]
+    lib.mmf_layernorm_f32_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]
     for name in SYMBOLS:
         getattr(lib, name)          # AttributeError here = header and .so disagree
     if lib.mmf_version() != 1:

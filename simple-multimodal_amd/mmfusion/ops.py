@@ -24,6 +24,30 @@ from .lib import (AttnProblem, GemmProblem, LnProblem, EPI_ACCUM, EPI_ADD_AUX, E
 
 BF16 = torch.bfloat16
 
+# --------------------------------------------------------------------------------------------
+# precision mode of the running root forward: "bf16" (default: bf16 storage, bf16 MFMA, f32 accumulate) or "fp32"
+# (parity mode: f32 storage, exact f32 MFMA — mmfusion.ops_f32).  Set by models.fusion_layers._FusionBase for the
+# duration of a root module's forward; the autograd Functions are separate per mode, so backward needs no flag.
+# --------------------------------------------------------------------------------------------
+_PRECISION = "bf16"
+
+
+def set_precision(mode: str) -> str:
+    global _PRECISION
+    if mode not in ("bf16", "fp32"):
+        raise ValueError(f"precision must be 'bf16' or 'fp32', got {mode!r}")
+    old, _PRECISION = _PRECISION, mode
+    return old
+
+
+def fp32_mode() -> bool:
+    return _PRECISION == "fp32"
+
+
+def _f32():
+    from . import ops_f32
+    return ops_f32
+
 
 # --------------------------------------------------------------------------------------------
 # parameter references
@@ -62,6 +86,8 @@ def shadow(p: torch.nn.Parameter) -> torch.Tensor:
     s = getattr(p, "_mmf_bf16", None)
     if s is None:
         raise RuntimeError("parameter is not arena-managed: call mmfusion.arena.ensure(module) first")
+    if _PRECISION == "fp32":
+        return p.detach()
     if p._mmf_late:
         p._mmf_arena.join()
     return s
@@ -208,6 +234,8 @@ def dropout(x: torch.Tensor, p: float, training: bool) -> torch.Tensor:
     """nn.Dropout(p) on a bf16 or fp32 tensor (identity when not training or p == 0)."""
     if not training or p <= 0.0:
         return x
+    if _PRECISION == "fp32":
+        raise RuntimeError("the fp32 parity mode runs without dropout (use p = 0 or eval())")
     if x.dtype not in (BF16, torch.float32):
         raise TypeError("dropout expects bf16 or fp32")
     return _Dropout.apply(x, float(p), next_site())
@@ -441,6 +469,9 @@ class _ToF32(torch.autograd.Function):
 
 
 def to_bf16(x: torch.Tensor) -> torch.Tensor:
+    """To the activation dtype of the running mode: bf16 (f32 in the fp32 parity mode)."""
+    if _PRECISION == "fp32":
+        return x if x.dtype == torch.float32 else _ToF32.apply(x)
     return x if x.dtype == BF16 else _ToBF16.apply(x)
 
 
@@ -619,6 +650,8 @@ class _GroupedLinear(torch.autograd.Function):
 def linear_group(items: Sequence[tuple], out_f32: bool = False, cat: bool = False):
     """items: (x_bf16 [M,K], LinearSpec, residual_bf16|None).  One NT launch for the group.  Returns the list of
     outputs, or with ``cat`` ONE (M, sum N_i) tensor whose column blocks are the outputs (equal M required)."""
+    if _PRECISION == "fp32":
+        return _f32().linear_group(items, cat)
     specs, tensors = [], []
     for x, spec, res in items:
         spec.has_residual = res is not None
@@ -687,6 +720,10 @@ class _GroupedFFN(torch.autograd.Function):
 def ffn_residual_group(items: Sequence[tuple], dropout_p: float = 0.0) -> List[torch.Tensor]:
     """items: (x_bf16 [M, d], linear1 (d -> 4d), linear2 (4d -> d)); returns x + ffn(x) per item.
     dropout_p > 0: nn.Dropout on the hidden activations (reference :198), fused into the first GEMM."""
+    if _PRECISION == "fp32":
+        if dropout_p > 0.0:
+            raise RuntimeError("the fp32 parity mode runs without dropout (use p = 0 or eval())")
+        return _f32().ffn_residual_group(items)
     layers, tensors = [], []
     for x, l1, l2 in items:
         for p in (l1.weight, l1.bias, l2.weight, l2.bias):
@@ -758,6 +795,8 @@ class _GroupedLayerNorm(torch.autograd.Function):
 
 def layernorm_group(items: Sequence[tuple], eps: float = 1e-5) -> List[torch.Tensor]:
     """items: (x_bf16 [..., d], gamma_param, beta_param)."""
+    if _PRECISION == "fp32":
+        return _f32().layernorm_group(items, eps)
     flat = []
     for x, g, b in items:
         flat += [x, g, b]
@@ -857,6 +896,10 @@ def attention_group(specs: List[AttnSpec], H: int, dh: int, srcs: Sequence[torch
     """Each (source, column) pair may be the k or v of several problems only if those problems'
     gradients are wanted separately — within one call every (source, column) range must be
     written by at most one problem's dK/dV (true for MulT: each block has its own K/V projection)."""
+    if _PRECISION == "fp32":
+        if dropout_p > 0.0:
+            raise RuntimeError("the fp32 parity mode runs without dropout (use p = 0 or eval())")
+        return _f32().attention_group(specs, H, dh, srcs)
     drop = (float(dropout_p), next_site()) if dropout_p > 0.0 else None
     return list(_GroupedAttention.apply(specs, H, dh, drop, *srcs))
 
@@ -882,6 +925,8 @@ class _Add3(torch.autograd.Function):
 
 
 def add3(a, b, c=None):
+    if _PRECISION == "fp32":
+        return a + b if c is None else a + b + c
     return _Add3.apply(a, b, c)
 
 
@@ -915,9 +960,46 @@ class _Add3Group(torch.autograd.Function):
 
 def add3_group(triples: Sequence[tuple]) -> List[torch.Tensor]:
     """[(a, b, c), ...] -> [a + b + c, ...], one launch (up to lib.ADD3_MAX sums)."""
+    if _PRECISION == "fp32":
+        return [a + b + c for a, b, c in triples]
     if not 0 < len(triples) <= lib.ADD3_MAX:
         raise ValueError(f"add3 group of {len(triples)} sums (1..{lib.ADD3_MAX})")
     return list(_Add3Group.apply(*[t for tr in triples for t in tr]))
+
+
+class _Fanout(torch.autograd.Function):
+    """n aliases of one bf16 tensor for n consumers; the backward receives all n gradients at once and sums them in
+    ONE pass (mmf_addn_bf16, f32 accumulate) instead of the n - 1 pairwise adds autograd would issue."""
+
+    @staticmethod
+    def forward(ctx, x, n: int):
+        ctx.n = n
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        live = [g for g in gs if g is not None]
+        if not live:
+            return None, None
+        if len(live) == 1:
+            return live[0], None
+        live = [g.contiguous() if g.dtype == BF16 else cast_to_bf16(g.contiguous()) for g in live]
+        out = torch.empty_like(live[0])
+        import ctypes as C
+        for i in range(0, len(live), lib.ADDN_MAX - 1):            # chunks of <= 8 operands (running sum carried)
+            chunk = live[i:i + lib.ADDN_MAX - 1] + ([out] if i > 0 else [])
+            if len(chunk) == 1:
+                chunk.append(torch.zeros_like(out))
+            ptrs = (C.c_void_p * len(chunk))(*[g.data_ptr() for g in chunk])
+            lib.check(lib.load().mmf_addn_bf16(ptrs, len(chunk), out.data_ptr(), out.numel(), 0, lib.stream_ptr()))
+        return out, None
+
+
+def fanout(x: torch.Tensor, n: int) -> List[torch.Tensor]:
+    """n handles on x (bf16) whose gradients are summed by one kernel.  Identity when x needs no gradient."""
+    if n < 2 or not x.requires_grad or x.dtype != BF16 or _PRECISION == "fp32":
+        return [x] * n
+    return list(_Fanout.apply(x, n))
 
 
 class _MeanPoolCat(torch.autograd.Function):
@@ -962,4 +1044,6 @@ class _MeanPoolCat(torch.autograd.Function):
 
 
 def meanpool_cat(xs: Sequence[torch.Tensor]) -> torch.Tensor:
+    if _PRECISION == "fp32":
+        return torch.cat([x.float().mean(dim=1) for x in xs], dim=-1)
     return _MeanPoolCat.apply(*xs)

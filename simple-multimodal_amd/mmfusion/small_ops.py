@@ -169,6 +169,21 @@ def gat3(h: torch.Tensor, att_src, att_dst, bias, B: int, heads: int, relu: bool
     return _Gat3.apply(h, att_src, att_dst, bias, B, heads, relu, pool, drop)
 
 
+def gat3_f32(h: torch.Tensor, att_src, att_dst, bias, B: int, heads: int, pool: bool = False):
+    """fp32 parity mode: relu(GATConv) on the 3-clique + self loops as f32 torch ops on the (B, 3) nodes (the same
+    dense arithmetic as csrc/small.hip gat3_*, reference :267-282 via PyG; parity unpinned).  h: f32 (B*3, heads*C)."""
+    Cc = h.shape[1] // heads
+    hh = h.view(B, 3, heads, Cc)
+    s_src = (hh * att_src.view(1, 1, heads, Cc)).sum(-1)
+    s_dst = (hh * att_dst.view(1, 1, heads, Cc)).sum(-1)
+    e = torch.nn.functional.leaky_relu(s_dst.unsqueeze(2) + s_src.unsqueeze(1), 0.2)       # (B, i, j, H)
+    ex = torch.exp(e - e.max(dim=2, keepdim=True).values)
+    alpha = ex / (ex.sum(dim=2, keepdim=True) + 1e-16)
+    y = torch.relu(torch.einsum("bijh,bjhc->bihc", alpha, hh).mean(dim=2) + bias)
+    rows = y.reshape(B * 3, Cc)
+    return (rows, y.mean(dim=1)) if pool else rows
+
+
 # --------------------------------------------------------------------------------------------
 # L2-normalise + symmetric InfoNCE of the three pairs
 # --------------------------------------------------------------------------------------------

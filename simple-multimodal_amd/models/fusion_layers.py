@@ -40,10 +40,17 @@ _MULT_STREAMS = int(_os.environ.get("MMF_MULT_STREAMS", "2"))       # MulT's cro
 class _FusionBase(nn.Module):
     """Arena handling shared by all fusion modules."""
 
+    def _precision(self) -> str:
+        """"bf16" (default) or "fp32" — the parity mode of mmfusion.ops_f32 (north_star "1e-3 fp32"): set
+        ``module.precision``, ``config.fusion_precision`` (dynamic attribute) or ``MMF_PRECISION``."""
+        return (getattr(self, "precision", None) or getattr(getattr(self, "config", None), "fusion_precision", None)
+                or _os.environ.get("MMF_PRECISION") or "bf16")
+
     def _enter(self):
         global _depth
         if _depth == 0:
             _arena.ensure(self, refresh=self.training)
+            self._saved_precision = ops.set_precision(self._precision())
             if self.training:
                 ops.begin_training_forward()        # new dropout masks for this step
         _depth += 1
@@ -52,6 +59,7 @@ class _FusionBase(nn.Module):
         global _depth
         _depth -= 1
         if _depth == 0:
+            ops.set_precision(getattr(self, "_saved_precision", "bf16"))
             _cat3_memo.clear()
             arena = getattr(next(self.parameters(), None), "_mmf_arena", None)
             if arena is not None:
@@ -143,12 +151,13 @@ class _MHAParams(nn.Module):
 # ------------------------------------------------------------------------------------------------
 def _cross_blocks(blocks: Sequence["CrossModalTransformer"], qs: Sequence[torch.Tensor],
                   kvs: Sequence[torch.Tensor], B: int, Tqs: Sequence[int], Tks: Sequence[int],
-                  p: float = 0.0) -> List[torch.Tensor]:
+                  p: float = 0.0, ress: Optional[Sequence[torch.Tensor]] = None) -> List[torch.Tensor]:
     """n independent CrossModalTransformer blocks (reference :202-211), one launch per stage.
-    qs[i]: bf16 (B*Tq_i, d); kvs[i]: bf16 (B*Tk_i, d)."""
+    qs[i]: bf16 (B*Tq_i, d); kvs[i]: bf16 (B*Tk_i, d); ress[i] (default qs[i]): the query rows as the residual of
+    :205 — a separate handle when the caller fans its input out (ops.fanout) to sum the input gradients in one pass."""
     proj = _cross_in_proj(blocks, qs, kvs)                           # [Q0, KV0, Q1, KV1, ...]
     att = _cross_attention(blocks, proj, B, Tqs, Tks, p)
-    return _cross_tail(blocks, att, qs, p)
+    return _cross_tail(blocks, att, qs if ress is None else ress, p)
 
 
 def _cross_in_proj(blocks, qs, kvs) -> List[torch.Tensor]:
@@ -291,8 +300,14 @@ class MultimodalTransformer(_FusionBase):
         t, a, v = _as_rows(text_features), _as_rows(audio_features), _as_rows(video_features)
         blocks = [self.text_to_audio, self.text_to_video, self.audio_to_text, self.audio_to_video,
                   self.video_to_text, self.video_to_audio]
-        qs, kvs, Tqs, Tks = [t, t, a, a, v, v], [a, v, t, v, t, a], [Tt, Tt, Ta, Ta, Tv, Tv], [Ta, Tv, Tt, Tv, Tt, Ta]
-        if _MULT_STREAMS > 1 and (_depth == 1 or _MULT_NESTED) and t.is_cuda:      # as the root module only: nested in HierarchicalFusion the
+        # every modality's rows are used seven times (2 queries + their residuals, 2 key/value sources, the three-way sum
+        # :156-158): fan them out so that the seven input-gradient contributions are summed by ONE kernel in backward
+        tf, af, vf = ops.fanout(t, 7), ops.fanout(a, 7), ops.fanout(v, 7)
+        qs, kvs = [tf[0], tf[1], af[0], af[1], vf[0], vf[1]], [af[2], vf[2], tf[2], vf[3], tf[3], af[3]]
+        ress = [tf[4], tf[5], af[4], af[5], vf[4], vf[5]]
+        Tqs, Tks = [Tt, Tt, Ta, Ta, Tv, Tv], [Ta, Tv, Tt, Tv, Tt, Ta]
+        t, a, v = tf[6], af[6], vf[6]
+        if _MULT_STREAMS > 1 and (_depth == 1 or _MULT_NESTED) and t.is_cuda and not ops.fp32_mode():      # as the root module only: nested in HierarchicalFusion the
             # branch stream already fills the holes, and a third stream measured slower (hier-seq 2.90 -> 3.24 ms)
             # The six blocks are independent: as balanced groups on concurrent streams, one group's HBM- / latency-bound
             # launches (attention, LayerNorm, residual adds, the partly filled last round of every GEMM launch) run
@@ -307,13 +322,13 @@ class MultimodalTransformer(_FusionBase):
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
                     r = _cross_blocks([blocks[i] for i in g], [qs[i] for i in g], [kvs[i] for i in g], B,
-                                      [Tqs[i] for i in g], [Tks[i] for i in g], p)
+                                      [Tqs[i] for i in g], [Tks[i] for i in g], p, [ress[i] for i in g])
                 for i, x in zip(g, r):
                     outs[i] = x
                 sides.append((side, g))
             g = groups[0]
             for i, x in zip(g, _cross_blocks([blocks[i] for i in g], [qs[i] for i in g], [kvs[i] for i in g], B,
-                                             [Tqs[i] for i in g], [Tks[i] for i in g], p)):
+                                             [Tqs[i] for i in g], [Tks[i] for i in g], p, [ress[i] for i in g])):
                 outs[i] = x
             for side, g in sides:
                 main.wait_stream(side)
@@ -321,7 +336,7 @@ class MultimodalTransformer(_FusionBase):
                     outs[i].record_stream(main)
             t_a, t_v, a_t, a_v, v_t, v_a = outs
         else:
-            t_a, t_v, a_t, a_v, v_t, v_a = _cross_blocks(blocks, qs, kvs, B, Tqs, Tks, p)    # :146-153
+            t_a, t_v, a_t, a_v, v_t, v_a = _cross_blocks(blocks, qs, kvs, B, Tqs, Tks, p, ress)    # :146-153
         et, ea, ev = ops.add3_group([(t, t_a, t_v), (a, a_t, a_v), (v, v_t, v_a)])         # :156-158, one launch
         # :161-168.  The self-attention outputs are only ever used through their mean over T, and the
         # out-projection is affine, so mean_t(out_proj(o_t)) == out_proj(mean_t o_t): pool the attention
@@ -370,6 +385,8 @@ class _DenseGAT(nn.Module):
         nodes, bf16 (B, out).  The linear map is an MFMA GEMM, everything else one fused kernel (csrc/small.hip
         gat3_*: scores, leaky-relu, 3-way softmax, dropout on alpha with p, aggregation, head mean, bias, ReLU)."""
         h = ops.linear(x, W(self.lin.weight), None, out_f32=True)                      # (B*3, heads*out) f32
+        if ops.fp32_mode():                      # parity mode: the (B, 3)-node arithmetic as f32 torch glue
+            return sops.gat3_f32(h, self.att_src, self.att_dst, self.bias, B, self.heads, pool=pool)
         return sops.gat3(h, self.att_src, self.att_dst, self.bias, B, self.heads, relu=True, pool=pool, dropout_p=p)
 
 
@@ -389,7 +406,10 @@ class GraphFusion(_FusionBase):
     def forward(self, text_features, audio_features, video_features) -> torch.Tensor:
         B = text_features.shape[0]
         c32, _ = _cat3(text_features, audio_features, video_features)
-        x = sops.stack3_embed(c32, self.node_type_embedding.weight)                    # :255-264, bf16 (B*3, d)
+        if ops.fp32_mode():
+            x = (c32.view(B, 3, -1) + self.node_type_embedding.weight).reshape(B * 3, -1)
+        else:
+            x = sops.stack3_embed(c32, self.node_type_embedding.weight)                # :255-264, bf16 (B*3, d)
         pg = _p(self, self.config.graph_dropout)
         pooled = None
         for l, layer in enumerate(self.gcn_layers):                                    # :280-282
@@ -475,7 +495,7 @@ class AdaptiveFusion(_FusionBase):
         att = ops.attention_group([AttnSpec(B, 3, 3, q=(0, 0), k=(0, d), v=(0, 2 * d))], H, dh, [qkv], dropout_p=p)[0]
         attended = ops.linear(att, *_wb(mp.out_proj), out_f32=True).view(B, 3, d)
         attn_w = torch.empty((B, 3, 3), dtype=torch.float32, device=qkv.device)        # head-averaged weights, returned
-        if H <= 16:                                                                    # for inspection only (no gradient)
+        if H <= 16 and not ops.fp32_mode():                                            # for inspection only (no gradient)
             from mmfusion import lib as _lib
             _lib.check(_lib.load().mmf_adaptive_attn_weights(qkv.data_ptr(), attn_w.data_ptr(), B, H, dh, _lib.stream_ptr()))
         else:
@@ -485,7 +505,11 @@ class AdaptiveFusion(_FusionBase):
                 attn_w = F.softmax(sc, dim=-1).mean(dim=1)
         hp = ops.linear(cat, *_wb(self.weight_predictor[0]), relu=True, out_f32=True)
         # :436-443: d -> 3 logits, softmax, weighted sum of the attended modalities — one kernel (small.hip ada_*)
-        weighted, aw = sops.adaptive_combine(hp, attended, self.weight_predictor[2].weight, self.weight_predictor[2].bias)
+        if ops.fp32_mode():                      # parity mode: d -> 3 logits, softmax, weighted sum as f32 torch glue
+            aw = F.softmax(F.linear(hp, self.weight_predictor[2].weight, self.weight_predictor[2].bias), dim=-1)
+            weighted = (attended * aw.unsqueeze(-1)).sum(dim=1)
+        else:
+            weighted, aw = sops.adaptive_combine(hp, attended, self.weight_predictor[2].weight, self.weight_predictor[2].bias)
         fused = ops.dropout(ops.linear(weighted, *_wb(self.fusion_layer[0]), relu=True, out_f32=True), p, True)
         return {"fused_features": fused, "attention_weights": attn_w, "adaptive_weights": aw}
 
@@ -519,7 +543,7 @@ class HierarchicalFusion(_FusionBase):
             d = text_features.shape[-1]
             pooled = ops.to_f32(ops.meanpool_cat([ops.to_bf16(x.contiguous()) for x in seq]))
             text_features, audio_features, video_features = pooled[:, :d], pooled[:, d:2 * d], pooled[:, 2 * d:]
-        if _BRANCH_STREAM and text_features.is_cuda:
+        if _BRANCH_STREAM and text_features.is_cuda and not ops.fp32_mode():
             # The four (B, d)-row branches are ~100 latency-bound launches of a few workgroups each and are independent
             # of the MulT branch: they run on a second stream beside MulT's chip-filling kernels (forward here; autograd
             # replays each node's backward on its forward stream) and join before the meta MLP.

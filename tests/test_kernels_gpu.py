@@ -788,3 +788,22 @@ def test_contrastive_fusion_large_batch_branch_matches_small_batch_kernel():
             assert l2 < 0.12, (B, l2)
         for p in P.values():
             p.grad = None
+
+
+@pytest.mark.parametrize("n", [2, 5, 7, 11])
+def test_fanout_sums_all_gradients_in_one_pass(n):
+    """ops.fanout: n handles on one bf16 tensor; the backward sums the n gradients with mmf_addn_bf16 (f32 accumulate,
+    one rounding) — compared with the f32 sum of the same bf16 gradients; n = 11 exercises the chunked form (> 8)."""
+    x = bf(rnd(333, 200, seed=1)).requires_grad_(True)            # 66,600 elements: vector body + scalar tail
+    hs = ops.fanout(x, n)
+    assert len(hs) == n and all(h.data_ptr() == x.data_ptr() for h in hs)
+    gs = [bf(rnd(333, 200, seed=10 + i)) for i in range(n)]
+    torch.autograd.backward(hs, gs)
+    want = sum(g.float() for g in gs)
+    assert x.grad.dtype == torch.bfloat16
+    tol = 2 ** -8 if n <= 8 else 2 ** -7                           # the chunked form rounds the running sum once more
+    assert rel(x.grad, want) < tol
+    if n <= 8:
+        assert torch.equal(x.grad, want.to(torch.bfloat16))        # exactly one rounding of the f32 sum
+    y = bf(rnd(8, 8, seed=2))                                      # no gradient wanted: plain aliases, no node
+    assert all(h is y for h in ops.fanout(y, 3))

@@ -53,8 +53,10 @@ def build_module(meta):
     return m.cuda().eval()      # as captured: eval mode (fixtures have p = 0; AdapterLayer's own 0.1 must be off)
 
 
-def run_hip(meta):
+def run_hip(meta, precision=None):
     m = build_module(meta)
+    if precision is not None:
+        m.precision = precision            # "fp32": the parity mode of mmfusion.ops_f32 (f32 storage, exact f32 MFMA)
     xs = [t.cuda().requires_grad_(True) for t in fixture_inputs(meta)]
     out = m(*xs, **meta.get("kwargs", {}))
     synth.probe_loss(out).backward()
@@ -102,6 +104,37 @@ def test_module_parity(name):
         assert l2_rel(gp[k], ref) <= tol, f"{name}: param grad {k} vs bf16-storage oracle L2 {l2_rel(gp[k], ref):.3e}"
 
 
+FP32_TOL = 1e-3        # BASELINE.json north_star: "within 1e-3 fp32"
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_module_parity_fp32_storage(name):
+    """The fp32-storage mode (module.precision = "fp32": f32 activations and weights in HBM, exact f32 MFMA GEMMs,
+    explicit-scores attention, f32 LayerNorm — mmfusion/ops_f32.py, csrc/gemmf32.hip) against the reference's own
+    vectors and the fp32 oracle at the north_star's fp32 tolerance: every output element within 1e-3 * max(1, |ref|max),
+    every input and parameter gradient within 1e-3 relative L2.  No ReLU-mask excuse in this mode."""
+    fx = load_fixture(name)
+    meta = fx.meta
+    out, gin, gp = run_hip(meta, precision="fp32")
+    o_out, o_gin, o_gp = oracle_fwd_bwd(meta)
+    worst = [0.0, 0.0, 0.0]
+    for k, ref in fx.out.items():
+        err = float((out[k] - ref).abs().max()) / max(1.0, float(ref.abs().max()))
+        worst[0] = max(worst[0], err)
+        assert err <= FP32_TOL, f"{name}: output {k} scaled abs err {err:.3e}"
+    for i, ref in enumerate(fx.gin):
+        worst[1] = max(worst[1], l2_rel(gin[i], ref))
+        assert l2_rel(gin[i], ref) <= FP32_TOL, f"{name}: input grad {i} L2 {l2_rel(gin[i], ref):.3e}"
+    scale = max(float(v.norm()) for v in o_gp.values())
+    for k, ref in o_gp.items():
+        if float(ref.norm()) <= 1e-7 * scale:                    # a gradient that is zero up to cancellation noise
+            assert float(gp[k].norm()) <= 1e-5 * scale, f"{name}: {k} should have (near-)zero grad"
+            continue
+        worst[2] = max(worst[2], l2_rel(gp[k], ref))
+        assert l2_rel(gp[k], ref) <= FP32_TOL, f"{name}: param grad {k} L2 {l2_rel(gp[k], ref):.3e}"
+    print(f"fp32 mode {name}: outputs {worst[0]:.2e}, input grads {worst[1]:.2e}, param grads {worst[2]:.2e}")
+
+
 def test_mult_at_the_bench_configuration_matches_oracle():
     """BASELINE.json configs[1] at its full size — B=16, T=512/400/30, d=768, H=8 (the workload bench.py times):
     every MulT output within 1e-2 * max(1, |ref|max) of the fp32 CPU oracle, input gradients by relative L2, and
@@ -122,11 +155,19 @@ def test_mult_at_the_bench_configuration_matches_oracle():
     torch.set_num_threads(16)
     ref = ref_cpu.multimodal_transformer(P, "", *xr, S["heads"])
     synth.probe_loss(ref).backward()
-    # the same with bf16 storage (oracle rounds where the HIP path stores bf16): the tight gradient check
+    # The tight check: the same arithmetic with bf16 storage (oracle rounds where the HIP path stores bf16).  Its loss
+    # leaves out `fused_features`: that output sits behind the ReLU of final_fusion over only B x d = 12,288 units, and
+    # ONE unit whose pre-activation lands on the other side of zero (|z| < ~1e-4 sigma; measured: a handful at this
+    # size) moves EVERY upstream gradient by ~1.3e-2 — the fp32 comparison above carries that path at its looser
+    # tolerance, the small fixtures carry it tightly (test_module_parity).  The three pooled projections reach every
+    # parameter below final_fusion: all nine attention cores, six cross blocks, pooling, out-projections.
+    def pooled_only(o):
+        return {k: v for k, v in o.items() if k != "fused_features"}
     Pb = {k: v.detach().clone().requires_grad_(True) for k, v in P.items()}
     xb = [x.clone().requires_grad_(True) for x in xs]
     with ref_cpu.bf16_storage():
-        synth.probe_loss(ref_cpu.multimodal_transformer(Pb, "", *xb, S["heads"])).backward()
+        ref_b = ref_cpu.multimodal_transformer(Pb, "", *xb, S["heads"])
+        synth.probe_loss(pooled_only(ref_b)).backward()
 
     m = m.cuda().eval()
 
@@ -144,20 +185,30 @@ def test_mult_at_the_bench_configuration_matches_oracle():
         got, want = out[k].detach().float().cpu(), want.detach()
         err = float((got - want).abs().max())
         assert err <= OUT_ATOL * max(1.0, float(want.abs().max())), f"{k}: abs err {err:.3e}"
-    for g, r, rb in zip(xg, xr, xb):
+    for g, r in zip(xg, xr):
         assert l2_rel(g.grad, r.grad) <= GIN_L2, f"input grad rel L2 {l2_rel(g.grad, r.grad):.3e}"
-        assert l2_rel(g.grad, rb.grad) <= GIN_L2_BF16, f"input grad vs bf16-storage oracle rel L2 {l2_rel(g.grad, rb.grad):.3e}"
     for name in ("final_fusion.0.weight", "text_to_audio.attention.in_proj_weight", "audio_to_text.ffn.3.weight"):
         got = dict(m.named_parameters())[name].grad.float().cpu()
         tol = GP_L2_RELU if any(t in name for t in RELU_FED) else GP_L2
         assert l2_rel(got, P[name].grad) <= tol, f"param grad {name}: {l2_rel(got, P[name].grad):.3e}"
+    for k, want in ref_b.items():                        # forward against the bf16-storage oracle
+        assert l2_rel(out[k], want) <= OUT_BF16, f"{k} vs bf16-storage oracle rel L2 {l2_rel(out[k], want):.3e}"
+    xg3 = [x.cuda().requires_grad_(True) for x in xs]
+    for p in m.parameters():
+        p.grad.zero_()
+    synth.probe_loss(pooled_only(m(*xg3))).backward()
+    torch.cuda.synchronize()
     worst = 0.0
-    for name, p in m.named_parameters():                 # EVERY parameter gradient against the bf16-storage oracle
+    for g, rb in zip(xg3, xb):
+        assert l2_rel(g.grad, rb.grad) <= GIN_L2_BF16, f"input grad vs bf16-storage oracle rel L2 {l2_rel(g.grad, rb.grad):.3e}"
+    for name, p in m.named_parameters():                 # EVERY parameter gradient below final_fusion
+        if name.startswith("final_fusion"):
+            continue
         e = l2_rel(p.grad.float().cpu(), Pb[name].grad)
         worst = max(worst, e)
         assert e <= GP_L2_BF16, f"param grad {name} vs bf16-storage oracle: {e:.3e}"
     print(f"bench config: worst parameter-gradient rel L2 vs bf16-storage oracle {worst:.3e}; input grads "
-          f"{[round(l2_rel(g.grad, rb.grad), 5) for g, rb in zip(xg, xb)]}")
+          f"{[round(l2_rel(g.grad, rb.grad), 5) for g, rb in zip(xg3, xb)]}")
     out2, xg2 = run()
     assert all(torch.equal(out[k], out2[k]) for k in out), "forward is not bit-reproducible"
     assert all(torch.equal(a.grad, b.grad) for a, b in zip(xg, xg2)), "backward is not bit-reproducible"
