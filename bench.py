@@ -15,8 +15,10 @@ model they are the outputs of the encoder tails, so the step computes the twelve
 the per-use input gradients as well.  `--frozen-inputs` times the round-1 variant (no input gradients); at N = 1 the
 default run reports that number too, as `frozen_inputs`, beside the headline.
 
-One "step" = fp32->bf16 weight-shadow cast, gradient-arena zeroing, forward, backward — and, for
-N > 1, the RCCL all-reduce (mean) of the flat gradient arena, the path's one exchange step.
+One "step" = gradient-arena zeroing, forward, backward — and, for N > 1, the RCCL all-reduce (mean) of the flat
+gradient arena, the path's one exchange step.  The bf16 weight shadow the MFMA kernels read is a cache of the fp32
+masters: fwd+bwd does not change them, so no cast runs in the step (--recast-weights puts round 1's whole-arena cast,
+~62 us, back into every step; in the train workload the fused AdamW kernel writes the shadow itself).
 Inputs are resident in HBM before the timed region.  Steps are replayed from one captured
 hipGraph unless --no-graph.  Rank 0 prints ONE JSON line.
 
@@ -130,9 +132,7 @@ def make_train_step(model, xs, arena, world, allreduce, rank):
 
 def make_step(workload, model, xs, arena):
     def step():
-        # the module's own entry hook re-casts the fp32 masters to the bf16 shadow on every training
-        # forward (what autocast does per forward), so the cast is inside the timed step; gradients are
-        # zeroed lazily: vectors by memset, matrices by the first wgrad GEMM of the step overwriting
+        # gradients are zeroed lazily: vectors by memset, matrices by the first wgrad GEMM of the step overwriting
         # (ParamArena.zero_grad(lazy=True); finalize_grads() zeroes any matrix no wgrad wrote)
         arena.zero_grad(overlap=True, lazy=True)
         for x in xs:
@@ -329,6 +329,10 @@ def main():
                          "(configs[2]); train: hier-seq training step incl. fused clip+AdamW (configs[3])")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--recast-weights", action="store_true",
+                    help="re-cast all fp32 master weights to the bf16 shadow inside every step (round-1 behaviour; the "
+                         "default casts only when a master changed: fwd+bwd leaves them unchanged, the fused AdamW of "
+                         "the train workload writes the shadow itself)")
     ap.add_argument("--frozen-inputs", action="store_true",
                     help="inputs do not require grad (round-1 variant: no in-projection dgrads, no input-gradient sums)")
     ap.add_argument("--profile-steps", type=int, default=5)
@@ -372,6 +376,9 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from mmfusion import arena as arena_mod, dp, synth
+    if args.recast_weights:
+        from models import fusion_layers as _flm
+        _flm._RECAST = True
     cfg, model, xs = build(args.workload, device, rank, args.dropout, input_grads=not args.frozen_inputs)
     arena = arena_mod.ensure(model)
     use_graph = not args.no_graph
@@ -573,6 +580,7 @@ def main():
                                 "train": "hier-seq training step (fwd+bwd+clip+AdamW)"}[args.workload] +
                                f", B=16/GPU, T_text=512 T_audio=400 T_frames=30 d=768 H=8, fusion_dropout={args.dropout:g}",
                    "input_gradients": not args.frozen_inputs,
+                   "weight_shadow": "re-cast every step" if args.recast_weights else "cached while the masters are unchanged",
                    "global_batch": B * world, "parallelism": f"dp{world}",
                    "grad_allreduce": (args.allreduce if world > 1 else None), "allreduce_overlaps_wgrad": bool(overlap),
                    "overlap_fallback": fallback["reason"], "graph_replay": bool(use_graph)},

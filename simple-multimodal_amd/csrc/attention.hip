@@ -42,6 +42,7 @@ __device__ __forceinline__ int find_problem(const AttnArgs& a, int bid) {
 // ================================================================================================
 // forward: workgroup = 128 query rows of one (b, h); wave = 32 query rows; KV tiles of 64 keys
 // ================================================================================================
+#ifdef MMF_LEGACY_KERNELS   // first-generation kernels: built with `make LEGACY=1` for A/B runs only
 template <int DH, bool DROP>
 __global__ __launch_bounds__(NT)
 void attn_fwd_kernel(const AttnArgs a) {
@@ -433,6 +434,8 @@ void attn_bwd_dkv_kernel(const AttnArgs a) {
   }
 }
 
+#endif  // MMF_LEGACY_KERNELS
+
 int validate(const char* who, const mmf_attn_problem* p, int n, int head_dim, bool bwd) {
   if (!p || n <= 0 || n > MMF_ATTN_MAX_PROBLEMS) MMF_FAIL(MMF_E_SHAPE, "%s: num_problems=%d out of range", who, n);
   if (head_dim != 64 && head_dim != 96) MMF_FAIL(MMF_E_UNSUPPORTED, "%s: head_dim=%d (supported: 64, 96)", who, head_dim);
@@ -454,6 +457,7 @@ int validate(const char* who, const mmf_attn_problem* p, int n, int head_dim, bo
   return MMF_OK;
 }
 
+#ifdef MMF_LEGACY_KERNELS
 int fill_args(AttnArgs& a, const mmf_attn_problem* p, int n, float scale, bool by_keys, float drop_p,
               const uint64_t* rng_state, uint32_t site) {
   a.nprob = n; a.scale = scale;
@@ -473,6 +477,7 @@ int fill_args(AttnArgs& a, const mmf_attn_problem* p, int n, float scale, bool b
   a.blk_start[n] = total;
   return total;
 }
+#endif  // MMF_LEGACY_KERNELS
 
 }  // namespace
 
@@ -481,11 +486,17 @@ int mmf_attn_fwd2_launch(const mmf_attn_problem* problems, int n, int head_dim, 
                          const uint64_t* rng_state, uint32_t site, hipStream_t s);
 int mmf_attn_bwd2_launch(const mmf_attn_problem* problems, int n, int head_dim, float scale, float drop_p,
                          const uint64_t* rng_state, uint32_t site, hipStream_t s);
+#ifdef MMF_LEGACY_KERNELS
 int mmf_attn_fwd3_launch(const mmf_attn_problem* problems, int n, int head_dim, float scale, float drop_p,
                          const uint64_t* rng_state, uint32_t site, hipStream_t s);
+#endif
 static int g_attn_impl = 0;       // 0 automatic, 1 first generation, 2 second generation, 3 third-generation forward
 extern "C" int mmf_attn_select_impl(int impl) {
   if (impl < 0 || impl > 3) MMF_FAIL(MMF_E_UNSUPPORTED, "mmf_attn_select_impl: impl=%d (0 auto, 1, 2, 3)", impl);
+#ifndef MMF_LEGACY_KERNELS
+  if (impl == 1 || impl == 3)
+    MMF_FAIL(MMF_E_UNSUPPORTED, "mmf_attn_select_impl: generation %d (superseded) is only in builds made with `make LEGACY=1`", impl);
+#endif
   g_attn_impl = impl;
   return MMF_OK;
 }
@@ -496,6 +507,10 @@ extern "C" int mmf_attn_fwd_grouped_ex(const mmf_attn_problem* problems, int num
   if (int rc = validate("mmf_attn_fwd_grouped", problems, num_problems, head_dim, false)) return rc;
   if (!(dropout_p >= 0.f) || dropout_p >= 1.f || (dropout_p > 0.f && !rng_state))
     MMF_FAIL(MMF_E_SHAPE, "mmf_attn_fwd_grouped_ex: dropout needs 0 <= p < 1 and an rng_state");
+#ifndef MMF_LEGACY_KERNELS
+  return mmf_attn_fwd2_launch(problems, num_problems, head_dim, scale, dropout_p, rng_state, site,
+                              static_cast<hipStream_t>(stream));
+#else
   if (g_attn_impl == 3)
     return mmf_attn_fwd3_launch(problems, num_problems, head_dim, scale, dropout_p, rng_state, site,
                                 static_cast<hipStream_t>(stream));
@@ -512,6 +527,7 @@ extern "C" int mmf_attn_fwd_grouped_ex(const mmf_attn_problem* problems, int num
                         else    hipLaunchKernelGGL((attn_fwd_kernel<64, false>), dim3(total), dim3(NT), 0, s, a); }
   MMF_CHECK_LAUNCH("mmf_attn_fwd_grouped");
   return MMF_OK;
+#endif
 }
 
 extern "C" int mmf_attn_bwd_grouped_ex(const mmf_attn_problem* problems, int num_problems, int head_dim,
@@ -521,6 +537,9 @@ extern "C" int mmf_attn_bwd_grouped_ex(const mmf_attn_problem* problems, int num
   if (!(dropout_p >= 0.f) || dropout_p >= 1.f || (dropout_p > 0.f && !rng_state))
     MMF_FAIL(MMF_E_SHAPE, "mmf_attn_bwd_grouped_ex: dropout needs 0 <= p < 1 and an rng_state");
   hipStream_t s = static_cast<hipStream_t>(stream);
+#ifndef MMF_LEGACY_KERNELS
+  return mmf_attn_bwd2_launch(problems, num_problems, head_dim, scale, dropout_p, rng_state, site, s);
+#else
   if (g_attn_impl != 1 && !getenv("MMF_ATTN_DEBUG"))
     return mmf_attn_bwd2_launch(problems, num_problems, head_dim, scale, dropout_p, rng_state, site, s);
   AttnArgs a;
@@ -538,6 +557,7 @@ extern "C" int mmf_attn_bwd_grouped_ex(const mmf_attn_problem* problems, int num
                         else    hipLaunchKernelGGL((attn_bwd_dkv_kernel<64, false>), dim3(total), dim3(NT), 0, s, a); }
   MMF_CHECK_LAUNCH("mmf_attn_bwd_grouped(dkv)");
   return MMF_OK;
+#endif
 }
 
 extern "C" int mmf_attn_fwd_grouped(const mmf_attn_problem* problems, int num_problems, int head_dim,

@@ -45,6 +45,7 @@ __device__ __forceinline__ int kr_off(int krow, int chunk) {         // [64][128
 
 // Stage one operand tile HBM -> registers.  KR == false: rows are the m/n index (count `rows`),
 // columns are k.  KR == true: rows are k, columns the m/n index.  Out-of-range chunks read as 0.
+#ifdef MMF_LEGACY_KERNELS   // first-generation 128x128 register-staged kernel: built with `make LEGACY=1` for A/B runs only
 template <bool KR>
 __device__ __forceinline__ void stage_load(u32x4_t (&r)[4], const unsigned short* __restrict__ base,
                                            int ld, int idx0, int idx_count, int k0, int K, int tid) {
@@ -239,13 +240,16 @@ int launch(const GemmArgs& a, int total_tiles, int out_f32, hipStream_t s) {
   return 0;
 }
 
+#endif  // MMF_LEGACY_KERNELS
 }  // namespace
 
 int mmf_gemm2_launch(const mmf_gemm_problem* problems, int num_problems, int layout, int epilogue,
                      int out_f32, const mmf_gemm_extra* extra, hipStream_t s);   // gemm2.hip: LDS-DMA ring kernel
 
+#ifdef MMF_LEGACY_KERNELS
 int mmf_gemm3_launch(const mmf_gemm_problem* problems, int num_problems, int layout, int epilogue,
                      int out_f32, hipStream_t s);      // gemm3.hip: persistent LDS-DMA ring kernel
+#endif
 int mmf_gemm4_launch(const mmf_gemm_problem* problems, int num_problems, int layout, int epilogue,
                      int out_f32, const mmf_gemm_extra* extra, hipStream_t s);   // gemm4.hip: 256x256 tile
 int mmf_gemm5_launch(const mmf_gemm_problem* problems, int num_problems, int layout, int epilogue,
@@ -256,7 +260,11 @@ int mmf_gemm5_launch(const mmf_gemm_problem* problems, int num_problems, int lay
 // form (gemm3.hip), 4 = 256x256 LDS-DMA ring (gemm4.hip).  Default from MMF_GEMM_IMPL, else automatic.
 static int g_gemm_impl = [] {
   const char* e = getenv("MMF_GEMM_IMPL");
-  return (e && e[0] >= '0' && e[0] <= '5') ? e[0] - '0' : 0;
+  int v = (e && e[0] >= '0' && e[0] <= '5') ? e[0] - '0' : 0;
+#ifndef MMF_LEGACY_KERNELS
+  if (v == 1 || v == 3) v = 0;
+#endif
+  return v;
 }();
 
 // Automatic choice between the two ring kernels.  The 256x256 tile does 25 % fewer LDS fragment reads,
@@ -287,6 +295,10 @@ static thread_local int t_last_impl = 0;
 extern "C" int mmf_gemm_last_impl(void) { return t_last_impl; }
 extern "C" int mmf_gemm_select_impl(int impl) {
   if (impl < 0 || impl > 5) MMF_FAIL(MMF_E_UNSUPPORTED, "mmf_gemm_select_impl: %d not in 0..5", impl);
+#ifndef MMF_LEGACY_KERNELS
+  if (impl == 1 || impl == 3)
+    MMF_FAIL(MMF_E_UNSUPPORTED, "mmf_gemm_select_impl: generation %d (superseded) is only in builds made with `make LEGACY=1`", impl);
+#endif
   g_gemm_impl = impl;
   return MMF_OK;
 }
@@ -356,6 +368,7 @@ extern "C" int mmf_gemm_grouped_ex(const mmf_gemm_problem* problems, int num_pro
     if (layout == MMF_GEMM_NT) return mmf_gemm5_launch(problems, num_problems, layout, epilogue, out_f32, extra, s);
     return mmf_gemm2_launch(problems, num_problems, layout, epilogue, out_f32, extra, s);
   }
+#ifdef MMF_LEGACY_KERNELS
   if (impl == 3) {
     bool wide_ok = true;              // the persistent kernel only has the 16-byte bf16 epilogue
     for (int i = 0; i < num_problems && !out_f32; ++i)
@@ -370,4 +383,8 @@ extern "C" int mmf_gemm_grouped_ex(const mmf_gemm_problem* problems, int num_pro
   }
   MMF_CHECK_LAUNCH("mmf_gemm_grouped");
   return MMF_OK;
+#else
+  (void)a; (void)total;
+  MMF_FAIL(MMF_E_UNSUPPORTED, "mmf_gemm_grouped: kernel generation %d is not in this build (make LEGACY=1)", impl);
+#endif
 }

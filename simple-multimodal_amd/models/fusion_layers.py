@@ -34,6 +34,7 @@ _depth = 0          # >0 while inside an outer fusion forward: the arena was alr
 import os as _os
 _BRANCH_STREAM = _os.environ.get("MMF_HIER_STREAMS", "1") != "0"   # HierarchicalFusion: small branches beside MulT
 _MULT_NESTED = _os.environ.get("MMF_MULT_NESTED", "0") == "1"      # A/B: the two groups also when MulT runs inside HierarchicalFusion
+_RECAST = _os.environ.get("MMF_RECAST_EACH_STEP", "0") == "1"        # fp32 -> bf16 weight cast in every training forward
 _MULT_STREAMS = int(_os.environ.get("MMF_MULT_STREAMS", "2"))       # MulT's cross blocks as this many concurrent groups (1, 2, 3)
 
 
@@ -49,7 +50,12 @@ class _FusionBase(nn.Module):
     def _enter(self):
         global _depth
         if _depth == 0:
-            _arena.ensure(self, refresh=self.training)
+            # The bf16 shadow is a cache of the fp32 masters: it is re-cast only when a parameter's version counter has
+            # moved (an in-place optimiser update, load_state_dict, ...) — the fused AdamW writes masters and shadow in
+            # one pass and needs no cast at all.  MMF_RECAST_EACH_STEP=1 restores the per-forward cast of every
+            # training forward (what autocast does; round 1's behaviour).  A captured hipGraph freezes this decision:
+            # a replayed step whose masters are modified from outside must call arena.refresh(force=True) itself.
+            _arena.ensure(self, refresh=self.training and _RECAST)
             self._saved_precision = ops.set_precision(self._precision())
             if self.training:
                 ops.begin_training_forward()        # new dropout masks for this step

@@ -104,15 +104,15 @@ def test_module_parity(name):
         assert l2_rel(gp[k], ref) <= tol, f"{name}: param grad {k} vs bf16-storage oracle L2 {l2_rel(gp[k], ref):.3e}"
 
 
-FP32_TOL = 1e-3        # BASELINE.json north_star: "within 1e-3 fp32"
+FP32_TOL = 1e-4        # BASELINE.json north_star asks "within 1e-3 fp32"; measured on MI355X <= 1e-6 outputs, <= 1.2e-5 grads
 
 
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_module_parity_fp32_storage(name):
     """The fp32-storage mode (module.precision = "fp32": f32 activations and weights in HBM, exact f32 MFMA GEMMs,
     explicit-scores attention, f32 LayerNorm — mmfusion/ops_f32.py, csrc/gemmf32.hip) against the reference's own
-    vectors and the fp32 oracle at the north_star's fp32 tolerance: every output element within 1e-3 * max(1, |ref|max),
-    every input and parameter gradient within 1e-3 relative L2.  No ReLU-mask excuse in this mode."""
+    vectors and the fp32 oracle, ten times inside the north_star's fp32 tolerance: every output element within
+    1e-4 * max(1, |ref|max), every input and parameter gradient within 1e-4 relative L2.  No ReLU-mask excuse here."""
     fx = load_fixture(name)
     meta = fx.meta
     out, gin, gp = run_hip(meta, precision="fp32")
@@ -209,6 +209,19 @@ def test_mult_at_the_bench_configuration_matches_oracle():
         assert e <= GP_L2_BF16, f"param grad {name} vs bf16-storage oracle: {e:.3e}"
     print(f"bench config: worst parameter-gradient rel L2 vs bf16-storage oracle {worst:.3e}; input grads "
           f"{[round(l2_rel(g.grad, rb.grad), 5) for g, rb in zip(xg3, xb)]}")
+    # and the fp32-storage mode at this size against the fp32 oracle, full probe loss, 1e-4 on everything
+    m.precision = "fp32"
+    out32, xg32 = run()
+    for k, want in ref.items():
+        err = float((out32[k].detach().float().cpu() - want.detach()).abs().max()) / max(1.0, float(want.abs().max()))
+        assert err <= FP32_TOL, f"fp32 mode: {k} scaled abs err {err:.3e}"
+    for g, r in zip(xg32, xr):
+        assert l2_rel(g.grad, r.grad) <= FP32_TOL, f"fp32 mode: input grad rel L2 {l2_rel(g.grad, r.grad):.3e}"
+    w32 = max(l2_rel(p.grad.float().cpu(), P[n].grad) for n, p in m.named_parameters())
+    assert w32 <= FP32_TOL, f"fp32 mode: worst parameter gradient rel L2 {w32:.3e}"
+    print(f"bench config, fp32 mode: worst parameter gradient rel L2 vs the fp32 oracle {w32:.3e}")
+    m.precision = None
+    out, xg = run()
     out2, xg2 = run()
     assert all(torch.equal(out[k], out2[k]) for k in out), "forward is not bit-reproducible"
     assert all(torch.equal(a.grad, b.grad) for a, b in zip(xg, xg2)), "backward is not bit-reproducible"

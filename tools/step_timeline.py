@@ -3,7 +3,8 @@
 
     python tools/step_timeline.py gpurun_out/r01b/stats profiles/r01b_step_timeline.txt [step_index]
 
-A step starts at the whole-arena fp32->bf16 weight cast; the 21st such step of the trace is a timed graph replay.
+A step starts at the gradient arena's hole-zeroing launch (zero_ranges_kernel, the first kernel of arena.zero_grad(lazy=True));
+the 21st such step of the trace is a timed graph replay.
 Columns: start (us from the step's first kernel), duration (us), hardware queue, kernel."""
 import collections
 import csv
@@ -21,7 +22,9 @@ def main():
     k = int(sys.argv[3]) if len(sys.argv) > 3 else 20
     f = glob.glob(os.path.join(src, "**", "*kernel_trace.csv"), recursive=True)[0]
     rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-    starts = [i for i, r in enumerate(rows) if "cast_f32_bf16_kernel" in r["Kernel_Name"] and int(r["Grid_Size_X"]) > 200000]
+    starts = [i for i, r in enumerate(rows) if "zero_ranges_kernel" in r["Kernel_Name"]]
+    if len(starts) <= k + 1:                    # older traces: the whole-arena weight cast opened every step
+        starts = [i for i, r in enumerate(rows) if "cast_f32_bf16_kernel" in r["Kernel_Name"] and int(r["Grid_Size_X"]) > 200000]
     step = rows[starts[k]:starts[k + 1]]
     t0 = int(step[0]["Start_Timestamp"])
     ev = [(int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0, r["Queue_Id"], short(r["Kernel_Name"])) for r in step]
