@@ -25,8 +25,8 @@
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = BM * BK * 2;          // 16 KiB per operand tile
-constexpr int NTHREADS = 256;
+[[maybe_unused]] constexpr int TILE_BYTES = BM * BK * 2;          // 16 KiB per operand tile
+[[maybe_unused]] constexpr int NTHREADS = 256;
 
 struct GemmArgs {
   int nprob;

@@ -1,11 +1,15 @@
+# Round profile collection on the GPU box:  TAG=r02 bash tools/prof_all.sh   (then: python tools/collect_profiles.py r02 "note")
 set -x
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cd $R
-O=gpurun_out/r01b
+TAG=${TAG:-r02}
+O=gpurun_out/$TAG
 mkdir -p $O
 timeout -k 10 120 python3 __graft_entry__.py smoke > $O/smoke.log 2>&1 || echo SMOKE_FAILED
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats --output-format csv -- python3 bench.py --steps 20 --warmup 5 > $O/bench_stats.log 2>&1
+export MMF_BENCH_NO_FROZEN=1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats --output-format csv -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_stats.log 2>&1
+python3 tools/step_timeline.py $O/stats $O/step_timeline.txt
 # PMC passes with the stream concurrency off (one launch per stage, as in bench.py's per-kernel timing pass)
 export MMF_MULT_STREAMS=1 MMF_HIER_STREAMS=0
 PM="python3 bench.py --steps 2 --warmup 1 --no-graph --profile-steps 1 --no-cpu-baseline"
@@ -15,8 +19,15 @@ timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_G
 unset MMF_MULT_STREAMS MMF_HIER_STREAMS
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats_hier --output-format csv -- python3 bench.py --workload hier --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_hier_stats.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats_train --output-format csv -- python3 bench.py --workload train --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_train_stats.log 2>&1
-timeout -k 10 200 python3 tools/attn_bench.py both > $O/attn_bench.log 2>&1
+MMF_ATTN_IMPLS=2 timeout -k 10 200 python3 tools/attn_bench.py both > $O/attn_bench.log 2>&1
 timeout -k 10 200 python3 tools/step_launches.py mult > $O/step_launches.log 2>&1
-python3 bench.py --steps 50 --warmup 10 > $O/bench_plain.log 2>&1
-python3 bench.py --steps 50 --warmup 10 --dropout 0.1 --no-cpu-baseline > $O/bench_dropout.log 2>&1
+unset MMF_BENCH_NO_FROZEN
+python3 bench.py > $O/bench_plain.log 2>&1
+python3 bench.py --dropout 0.1 --no-cpu-baseline > $O/bench_dropout.log 2>&1
+python3 bench.py --workload hier --no-cpu-baseline > $O/bench_hier.log 2>&1
+python3 bench.py --workload train --no-cpu-baseline > $O/bench_train.log 2>&1
+ORACLE_STORAGE=bf16 TOPK=4 python3 tools/parity_report.py > $O/parity_bf16.txt 2>&1
+TOPK=4 python3 tools/parity_report.py > $O/parity_fp32.txt 2>&1
+# keep what travels back small: the raw traces of the three --stats runs are summarised above
+rm -f $O/stats_hier/*/*kernel_trace.csv $O/stats_train/*/*kernel_trace.csv
 ls $O
