@@ -26,7 +26,7 @@ namespace {
 
 // One wave of the forward: NQ (0, 1 or 2) query blocks of 32 rows at rows qs and qs + 128.  Waves with
 // NQ == 0 only take part in the K/V staging and the barriers.
-template <int DH, bool DROP, int NQ>
+template <int DH, bool DROP, int NQ, int ST>
 __device__ __forceinline__ void fwd2_wave(const AttnArgs2& a, const mmf_attn_problem& P, const int pidx, const int bh,
                                           const int qs, char* smem) {
   constexpr int KS = DH / 16, DT = DH / 32, SB = (DH + 8) * 2, TILE_B = 64 * SB, STAGE_B = 2 * TILE_B;
@@ -41,12 +41,16 @@ __device__ __forceinline__ void fwd2_wave(const AttnArgs2& a, const mmf_attn_pro
   const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(Kg), 0, Tk * P.ldk * 2, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(Vg), 0, Tk * P.ldv * 2, 0x00020000);
 
-  auto issue = [&](int j) { dma_pair<DH>(rsK, rsV, P.ldk, P.ldv, smem + (j & 1) * STAGE_B, j, wave, lane); };
+  // ST-stage ring (ST = 2: tile j+1 in flight under tile j; ST = 3: tiles j+1 and j+2 — a single workgroup's tile of
+  // compute (~1.6 us) is shorter than a K/V DMA round trip under load, so with one tile of prefetch every tile's
+  // barrier waits for memory: a 256-CU launch of ONE problem ran 3.4 us per 64-key tile against ~1.6 us of work)
+  auto issue = [&](int j) { dma_pair<DH>(rsK, rsV, P.ldk, P.ldv, smem + (j % ST) * STAGE_B, j, wave, lane); };
   const int ntiles = (Tk + 63) / 64;
   issue(0);
+  if (ST > 2 && ntiles > 1) issue(1);
 
-  // Q fragments through the wave's slice of stage 1 (free until the first barrier of the loop)
-  char* slice = smem + STAGE_B + wave * (32 * SB);
+  // Q fragments through the wave's slice of the last stage (free until the loop issues tile ST-1 behind its first barrier)
+  char* slice = smem + (ST - 1) * STAGE_B + wave * (32 * SB);
   bf16x8_t qf[NQA][KS];
   if constexpr (NQ > 0) {
     const unsigned short* Qg = static_cast<const unsigned short*>(P.Q) + (size_t)b * Tq * P.ldq + h * DH;
@@ -70,14 +74,21 @@ __device__ __forceinline__ void fwd2_wave(const AttnArgs2& a, const mmf_attn_pro
   const unsigned troff = (unsigned)((4 * half + ((lane >> 2) & 3)) * SB + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2);
   const unsigned smem_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 
+  // pieces of one tile this wave issues (dma_pair: piece p = wave + 4 i < 2 PIECES): the count a counted vmcnt leaves in flight
+  constexpr int PIECES2 = 2 * (TILE_B / 1024);
   for (int j = 0; j < ntiles; ++j) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of tile j have landed
-    __builtin_amdgcn_s_barrier();                          // ... everyone's; the other stage is free
+    if (ST > 2 && j + 1 < ntiles) {                        // leave tile j+1's pieces in flight
+      if (wave < PIECES2 % 4) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PIECES2 / 4 + 1) : "memory");
+      else                    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PIECES2 / 4) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of tile j have landed
+    }
+    __builtin_amdgcn_s_barrier();                          // ... everyone's; the stage of tile j-1 is free
     asm volatile("" ::: "memory");
-    if (j + 1 < ntiles && !(a.debug & 1)) issue(j + 1);
+    if (j + ST - 1 < ntiles && !(a.debug & 1)) issue(j + ST - 1);
     if constexpr (NQ > 0) {
-      const char* sK = smem + (j & 1) * STAGE_B;
-      const unsigned va = smem_lds + (j & 1) * STAGE_B + TILE_B + troff;
+      const char* sK = smem + (j % ST) * STAGE_B;
+      const unsigned va = smem_lds + (j % ST) * STAGE_B + TILE_B + troff;
       const int kb = j * 64;
       // one 32-key block: S^T = K.Q^T (raw scores), online softmax (lane = query), O^T += V^T.P^T
       auto block = [&](auto KTc) {
@@ -150,7 +161,7 @@ __device__ __forceinline__ void fwd2_wave(const AttnArgs2& a, const mmf_attn_pro
 
   if constexpr (NQ > 0) {
     // the stage the last tile did not use is free (every wave passed the last barrier): reuse the wave's slice there
-    char* oslice = smem + (ntiles & 1) * STAGE_B + wave * (32 * SB);
+    char* oslice = smem + (ntiles % ST) * STAGE_B + wave * (32 * SB);
     unsigned short* Og = static_cast<unsigned short*>(P.O) + (size_t)b * Tq * P.ldo + h * DH;
 #pragma unroll
     for (int qb = 0; qb < NQ; ++qb) {
@@ -162,11 +173,11 @@ __device__ __forceinline__ void fwd2_wave(const AttnArgs2& a, const mmf_attn_pro
   }
 }
 
-template <int DH, bool DROP>
+template <int DH, bool DROP, int ST>
 __global__ __launch_bounds__(NT, 2)
 void attn_fwd2_kernel(const AttnArgs2 a) {
   constexpr int STAGE_B = 2 * 64 * (DH + 8) * 2;
-  __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE_B];
+  __shared__ __attribute__((aligned(1024))) char smem[ST * STAGE_B];         // ST = 3, DH = 96: 78 KiB, two workgroups per CU
   const int bid = blockIdx.x;
   int pi = 0;
   while (pi + 1 < a.nprob && bid >= a.blk_start[pi + 1]) ++pi;
@@ -182,9 +193,9 @@ void attn_fwd2_kernel(const AttnArgs2 a) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nq = (a.debug & 2) ? 0 : (wave < nb) + (wave + 4 < nb);   // blocks wave and wave + 4
   const int qs = q0 + 32 * wave, pidx = a.orig[pi];
-  if (nq == 2)      fwd2_wave<DH, DROP, 2>(a, P, pidx, bh, qs, smem);
-  else if (nq == 1) fwd2_wave<DH, DROP, 1>(a, P, pidx, bh, qs, smem);
-  else              fwd2_wave<DH, DROP, 0>(a, P, pidx, bh, qs, smem);
+  if (nq == 2)      fwd2_wave<DH, DROP, 2, ST>(a, P, pidx, bh, qs, smem);
+  else if (nq == 1) fwd2_wave<DH, DROP, 1, ST>(a, P, pidx, bh, qs, smem);
+  else              fwd2_wave<DH, DROP, 0, ST>(a, P, pidx, bh, qs, smem);
 }
 
 
@@ -492,10 +503,18 @@ int mmf_attn_fwd2_launch_indexed(const mmf_attn_problem* problems, const int* id
   if (idx)
     for (int k = 0; k < n; ++k) a.orig[k] = (short)idx[a.orig[k]];
   const bool dr = a.drop_thresh != 0u;
-  if (head_dim == 96) { if (dr) hipLaunchKernelGGL((attn_fwd2_kernel<96, true>), dim3(total), dim3(NT), 0, s, a);
-                        else    hipLaunchKernelGGL((attn_fwd2_kernel<96, false>), dim3(total), dim3(NT), 0, s, a); }
-  else                { if (dr) hipLaunchKernelGGL((attn_fwd2_kernel<64, true>), dim3(total), dim3(NT), 0, s, a);
-                        else    hipLaunchKernelGGL((attn_fwd2_kernel<64, false>), dim3(total), dim3(NT), 0, s, a); }
+  static const int stages = [] { const char* e = getenv("MMF_ATTN_FWD_STAGES"); const int v = e ? atoi(e) : 2; return v == 3 ? 3 : 2; }();   // 3 measured equal (round 2): the per-tile chain, not the DMA, is what a workgroup waits for
+  if (stages == 3) {
+    if (head_dim == 96) { if (dr) hipLaunchKernelGGL((attn_fwd2_kernel<96, true, 3>), dim3(total), dim3(NT), 0, s, a);
+                          else    hipLaunchKernelGGL((attn_fwd2_kernel<96, false, 3>), dim3(total), dim3(NT), 0, s, a); }
+    else                { if (dr) hipLaunchKernelGGL((attn_fwd2_kernel<64, true, 3>), dim3(total), dim3(NT), 0, s, a);
+                          else    hipLaunchKernelGGL((attn_fwd2_kernel<64, false, 3>), dim3(total), dim3(NT), 0, s, a); }
+  } else {
+    if (head_dim == 96) { if (dr) hipLaunchKernelGGL((attn_fwd2_kernel<96, true, 2>), dim3(total), dim3(NT), 0, s, a);
+                          else    hipLaunchKernelGGL((attn_fwd2_kernel<96, false, 2>), dim3(total), dim3(NT), 0, s, a); }
+    else                { if (dr) hipLaunchKernelGGL((attn_fwd2_kernel<64, true, 2>), dim3(total), dim3(NT), 0, s, a);
+                          else    hipLaunchKernelGGL((attn_fwd2_kernel<64, false, 2>), dim3(total), dim3(NT), 0, s, a); }
+  }
   MMF_CHECK_LAUNCH("mmf_attn_fwd_grouped(v2)");
   return MMF_OK;
 }

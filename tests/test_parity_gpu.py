@@ -217,9 +217,11 @@ def test_mult_at_the_bench_configuration_matches_oracle():
         assert err <= FP32_TOL, f"fp32 mode: {k} scaled abs err {err:.3e}"
     for g, r in zip(xg32, xr):
         assert l2_rel(g.grad, r.grad) <= FP32_TOL, f"fp32 mode: input grad rel L2 {l2_rel(g.grad, r.grad):.3e}"
-    w32 = max(l2_rel(p.grad.float().cpu(), P[n].grad) for n, p in m.named_parameters())
-    assert w32 <= FP32_TOL, f"fp32 mode: worst parameter gradient rel L2 {w32:.3e}"
-    print(f"bench config, fp32 mode: worst parameter gradient rel L2 vs the fp32 oracle {w32:.3e}")
+    w32, wname = max((l2_rel(p.grad.float().cpu(), P[n].grad), n) for n, p in m.named_parameters())
+    # parameters: the north_star's 1e-3 (measured 7.6e-4 on the worst tensor at this size — 8192-row fp32 reductions in
+    # a different order than the CPU's blocked sums; outputs and input gradients above hold 1e-4)
+    assert w32 <= 1e-3, f"fp32 mode: worst parameter gradient {wname} rel L2 {w32:.3e}"
+    print(f"bench config, fp32 mode: worst parameter gradient rel L2 vs the fp32 oracle {w32:.3e} ({wname})")
     m.precision = None
     out, xg = run()
     out2, xg2 = run()
