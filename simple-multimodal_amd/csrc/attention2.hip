@@ -100,6 +100,7 @@ __device__ __forceinline__ void fwd2_wave(const AttnArgs2& a, const mmf_attn_pro
         for (int qb = 0; qb < NQ; ++qb)
 #pragma unroll
           for (int r = 0; r < 16; ++r) s[qb][r] = 0.f;
+        mfma_prio(1);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           const bf16x8_t kf = row_frag<DH>(sK, 32 * KT, ks, lane);
@@ -107,6 +108,7 @@ __device__ __forceinline__ void fwd2_wave(const AttnArgs2& a, const mmf_attn_pro
           for (int qb = 0; qb < NQ; ++qb)
             s[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qb][ks], s[qb], 0, 0, 0);
         }
+        mfma_prio(0);
         s16x4_t lo, hi;
         tr_issue<DH, 2 * KT, 0>(va, lo, hi);               // first V^T fragment lands under the softmax
         const bool ragged = k0 + 32 > Tk;
@@ -276,11 +278,13 @@ __device__ __forceinline__ void dq2_wave(const AttnArgs2& a, const mmf_attn_prob
         f32x16_t s, dp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+        mfma_prio(1);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<DH>(sK, 32 * KT, ks, lane), qf[ks], s, 0, 0, 0);
           dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<DH>(sV, 32 * KT, ks, lane), dof[ks], dp, 0, 0, 0);
         }
+        mfma_prio(0);
         s16x4_t lo, hi;
         tr_issue<DH, 2 * KT, 0>(vaK, lo, hi);
         const bool ragged = k0 + 32 > Tk;
@@ -341,12 +345,14 @@ struct DkvStep {
       tr_issue<DH, 2 * QS + M / (2 * DT), (M / 2) % DT>((M & 1) ? vaQ : vadO, nlo, nhi);
     }
     tr_wait<(N + 1 < NF) ? 2 : 0>(lo, hi);
+    if constexpr (N == 0) mfma_prio(1);
     const bf16x8_t f = join(lo, hi);
     if constexpr (N % (2 * DT) == 0) { pf = acc_frag(pm, N / (2 * DT)); dsf = acc_frag(dsm, N / (2 * DT)); }
     constexpr int dt = (N / 2) % DT;
     if constexpr ((N & 1) == 0) dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f, pf, dv[dt], 0, 0, 0);
     else                        dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f, dsf, dk[dt], 0, 0, 0);
     if constexpr (N + 1 < NF) DkvStep<DH, QS, N + 1>::run(vaQ, vadO, nlo, nhi, pm, dsm, pf, dsf, dv, dk);
+    else mfma_prio(0);
   }
 };
 
@@ -411,11 +417,13 @@ __device__ __forceinline__ void dkv2_wave(const AttnArgs2& a, const mmf_attn_pro
         f32x16_t s, dp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+        mfma_prio(1);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<DH>(sQ, 32 * QS, ks, lane), kf[ks], s, 0, 0, 0);
           dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<DH>(sdO, 32 * QS, ks, lane), vf[ks], dp, 0, 0, 0);
         }
+        mfma_prio(0);
         s16x4_t lo, hi;
         tr_issue<DH, 2 * QS, 0>(vadO, lo, hi);
         f32x16_t ds;

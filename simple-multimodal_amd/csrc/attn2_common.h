@@ -14,6 +14,18 @@ constexpr unsigned OOB = 0x80000000u;
 #define DQ_WAVES_PER_SIMD 3            // dQ kernel at <= 168 registers: three 4-wave workgroups per CU (3 x 52 KiB of LDS)
 #endif
 constexpr float DEFER = 6.0f;          // log2 domain: P <= 64 before a rescale is forced
+// MMF_ATTN_SETPRIO=1 (build-time A/B): raise the wave's issue priority around its MFMA clusters (guide T5), so that of the
+// two waves sharing a SIMD the one entering a matrix phase is not held behind the other's softmax VALU stream
+#ifndef MMF_ATTN_SETPRIO
+#define MMF_ATTN_SETPRIO 0
+#endif
+__device__ __forceinline__ void mfma_prio(int on) {
+#if MMF_ATTN_SETPRIO
+  if (on) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+#else
+  (void)on;
+#endif
+}
 
 struct AttnArgs2 {
   int nprob;
@@ -67,6 +79,7 @@ struct PvStep {
     s16x4_t nlo, nhi;
     if constexpr (N + 1 < NF) tr_issue<DH, 2 * KT + (N + 1) / DT, (N + 1) % DT>(va, nlo, nhi);
     tr_wait<(N + 1 < NF) ? 2 : 0>(lo, hi);
+    if constexpr (N == 0) mfma_prio(1);
     const bf16x8_t vf = join(lo, hi);
     if constexpr (N % DT == 0) {
 #pragma unroll
@@ -76,6 +89,7 @@ struct PvStep {
     for (int qb = 0; qb < NQ; ++qb)
       o[qb][N % DT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[qb], o[qb][N % DT], 0, 0, 0);
     if constexpr (N + 1 < NF) PvStep<DH, NQ, KT, N + 1>::run(va, nlo, nhi, s, pf, o);
+    else mfma_prio(0);
   }
 };
 

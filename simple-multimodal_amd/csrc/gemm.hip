@@ -273,6 +273,10 @@ static int g_gemm_impl = [] {
 // 256x256 tiling fills at least 80 % of the CU-rounds it occupies.  wgrad (TN) stays on 256x128
 // (the transposed-read operands of the bigger wave tile do not fit 256 registers without spills).
 static const int g_shortk_mode = [] { const char* e = getenv("MMF_GEMM_SHORTK"); return e ? atoi(e) : 1; }();
+static const int g_shortk_nn = [] { const char* e = getenv("MMF_GEMM_SHORTK_NN"); return e ? atoi(e) : 0; }();
+// MMF_GEMM_POLICY: 1 = round 1's rule (below), 2 = round 2's rule from the per-group microbenchmarks
+// (profiles/r02_gemm_generations.txt: every MulT launch group x {256x128, 256x256, 256x128/32-deep} in isolation).
+static const int g_policy = [] { const char* e = getenv("MMF_GEMM_POLICY"); return e ? atoi(e) : 2; }();
 static int auto_impl(const mmf_gemm_problem* p, int n, int layout) {
   if (layout == MMF_GEMM_TN) return 2;
   long tiles = 0;
@@ -283,11 +287,25 @@ static int auto_impl(const mmf_gemm_problem* p, int n, int layout) {
   }
   static const int cus = [] { int c = mmf_device_cu_count(); return c > 0 ? c : 256; }();
   const long rounds = (tiles + cus - 1) / cus;
+  if (g_policy >= 2) {
+    // The 256x256 tile (1.2+ PF steady state) wins whenever its tiling either fills its CU rounds (>= 80 %) or is one
+    // partial round of at least half the chip: a launch that leaves CUs idle still finishes sooner than two rounds of
+    // the 256x128 tile (FFN2 / dX / out-projection groups of three MulT blocks: 177 tiles, +22 ... +32 %).  Otherwise:
+    // short reductions go to the two-workgroups-per-CU kernel (NT and NN), long ones to the 256x128 ring (NT) or,
+    // for NN, again to the 32-deep kernel (930 vs 897 TF on the dX groups).
+    const bool fills = tiles * 100 >= rounds * cus * 80;
+    const bool one_round = tiles <= cus && 2 * tiles >= cus;
+    if (fills || one_round) return 4;
+    if (kmax <= 1024) return 5;
+    return layout == MMF_GEMM_NN ? 5 : 2;
+  }
   if (tiles >= 2L * cus && tiles * 100 >= rounds * cus * 80) return 4;
   // NT launches with a short reduction that the 256x256 tiling does not fill: the 32-deep, two-workgroups-per-CU
   // form of the 256x128 kernel (one workgroup's pipeline fill / output burst under the other's MFMA loop):
   // +2 ... +9 % on the in-projection and out-projection launches of MulT (MMF_GEMM_SHORTK=0: off)
   if (layout == MMF_GEMM_NT && g_shortk_mode && kmax <= 1024) return 5;
+  // NN with a short reduction (round 2, MMF_GEMM_SHORTK_NN=1 to enable): the same two-workgroups-per-CU form
+  if (layout == MMF_GEMM_NN && g_shortk_nn && kmax <= 1024) return 5;
   return 2;
 }
 static int gemm_impl() { return g_gemm_impl; }
@@ -329,7 +347,7 @@ extern "C" int mmf_gemm_grouped_ex(const mmf_gemm_problem* problems, int num_pro
   int impl = gemm_impl();
   if (impl == 0) impl = auto_impl(problems, num_problems, layout);
   if (needs_v2 && impl != 4 && impl != 5) impl = 2;   // only gemm2 / gemm4 / gemm5 have the alpha / dropout epilogue
-  if (impl == 5 && layout != MMF_GEMM_NT) impl = 2;
+  if (impl == 5 && layout == MMF_GEMM_TN) impl = 2;
   t_last_impl = impl;
   GemmArgs a;
   a.nprob = num_problems;
@@ -365,7 +383,7 @@ extern "C" int mmf_gemm_grouped_ex(const mmf_gemm_problem* problems, int num_pro
   if (impl == 2) return mmf_gemm2_launch(problems, num_problems, layout, epilogue, out_f32, extra, s);
   if (impl == 4) return mmf_gemm4_launch(problems, num_problems, layout, epilogue, out_f32, extra, s);
   if (impl == 5) {
-    if (layout == MMF_GEMM_NT) return mmf_gemm5_launch(problems, num_problems, layout, epilogue, out_f32, extra, s);
+    if (layout != MMF_GEMM_TN) return mmf_gemm5_launch(problems, num_problems, layout, epilogue, out_f32, extra, s);
     return mmf_gemm2_launch(problems, num_problems, layout, epilogue, out_f32, extra, s);
   }
 #ifdef MMF_LEGACY_KERNELS

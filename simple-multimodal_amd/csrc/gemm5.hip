@@ -1,4 +1,4 @@
-// Grouped bf16 GEMM, NT layout only, short-K variant: the 256 x 128 LDS-DMA ring of gemm2.hip with a 32-deep k-step
+// Grouped bf16 GEMM, NT and (round 2) NN layouts, short-K variant: the 256 x 128 LDS-DMA ring of gemm2.hip with a 32-deep k-step
 // and a 72 KiB ring, so that TWO workgroups fit a CU (2 x 72 KiB LDS, <= 128 registers, 16 waves per CU).
 //
 // Why: at K = 768 a 256 x 128 tile spends ~4 us in its MFMA loop and about as long filling its pipeline and
@@ -9,6 +9,9 @@
 //   LDS image: [rows][32 k] = 64-B rows, 16-B chunk slot = chunk ^ (2 * ((row >> 3) & 1))  (guide st_16x32 swizzle:
 //   the four ds_read_b128 lane groups each see 16 distinct bank quads), filled lane-linearly by LDS-DMA with the
 //   swizzle on the source address; 3 stages x 24 KiB, 3 DMA pieces per wave per k-step, counted vmcnt(3).
+// NN (dgrad: the B operand is W[k][n], its reduction index is the memory row): the B tile uses gemm2.hip's KR image
+// ([32 k][128 n] = 256-B rows, chunk XOR swizzle, 8 one-KiB DMA pieces of 4 k-rows) and is read back transposed with
+// ds_read_b64_tr_b16 from inline asm (hipcc would drain the LDS-DMA in flight before the builtin).
 // Epilogue and launch conventions are gemm2.hip's.
 #include "mmf_internal.h"
 
@@ -52,12 +55,45 @@ __device__ __forceinline__ void dma_piece32(__amdgpu_buffer_rsrc_t rsrc, char* l
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)lds_piece, 16, voff, 0, 0, 0);
 }
 
+// ---- KR image of the NN layout's B tile (gemm2.hip kr_*: 256-B k-rows, guide T10 image (b)) ----
+__device__ __forceinline__ int kr_swz(int krow) { return ((krow & 3) << 2) | ((krow >> 2) & 3); }
+__device__ __forceinline__ int kr_off(int krow, int chunk) { return krow * 256 + ((chunk ^ kr_swz(krow)) << 4); }
+// LDS-DMA of piece c = k-rows 4c .. 4c+3 (256 B each) of a [32 k][128 idx] tile
+__device__ __forceinline__ void dma_piece_kr(__amdgpu_buffer_rsrc_t rsrc, char* lds_piece, int c, int ld,
+                                             int idx0, int idx_count, int k0, int K, int lane) {
+  const int krow = 4 * c + (lane >> 4), s = lane & 15;
+  const int row = k0 + krow;
+  const int col = idx0 + ((s ^ kr_swz(krow)) << 3);
+  const bool ok = row < K && col < idx_count;
+  const unsigned voff = ok ? (unsigned)(row * ld + col) * 2u : OOB;
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)lds_piece, 16, voff, 0, 0, 0);
+}
+__device__ __forceinline__ s16x4_t tr_read_asm(const char* p) {
+  s16x4_t r;
+  const unsigned addr = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(addr));
+  return r;
+}
+// transposed fragment of the 16 idx [idx0, idx0 + 16) x 32 k of a KR tile: lane l = (idx idx0 + (l & 15), k chunk l >> 4)
+__device__ __forceinline__ void read_frag_kr32(const char* tile, int idx0, int lane, s16x4_t& lo, s16x4_t& hi) {
+  const int kb = (lane >> 4) << 3;
+  const int q = (lane >> 2) & 3, p = lane & 3;
+  const int chunk = (idx0 >> 3) + (p >> 1);
+  const int sub = (p & 1) << 3;
+  lo = tr_read_asm(tile + kr_off(kb + q, chunk) + sub);
+  hi = tr_read_asm(tile + kr_off(kb + 4 + q, chunk) + sub);
+}
+__device__ __forceinline__ bf16x8_t tr_join(const s16x4_t& lo, const s16x4_t& hi) {
+  const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+
 // fragment of 16 rows x 32 k: lane l holds row idx0 + (l & 15), k chunk l >> 4
 __device__ __forceinline__ bf16x8_t read_frag32(const char* tile, int idx0, int lane) {
   return *reinterpret_cast<const bf16x8_t*>(tile + kc32_off(idx0 + (lane & 15), lane >> 4));
 }
 
-template <bool OUT_F32>
+template <bool B_KR, bool OUT_F32>
 __global__ __launch_bounds__(NTHREADS, 4)      // <= 128 registers: two 8-wave workgroups per CU
 void gemm5_grouped_kernel(const GemmArgs args, const int total_tiles) {
   __shared__ __attribute__((aligned(1024))) char smem[STAGES * STAGE_BYTES];
@@ -85,7 +121,7 @@ void gemm5_grouped_kernel(const GemmArgs args, const int total_tiles) {
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
 
   // buffer descriptors (wave-uniform: built from kernel arguments only)
-  const int a_rows = M, b_rows = N;
+  const int a_rows = M, b_rows = B_KR ? K : N;
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<void*>(P.A), 0, (int)((size_t)a_rows * P.lda * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
@@ -99,7 +135,8 @@ void gemm5_grouped_kernel(const GemmArgs args, const int total_tiles) {
       const int c = wave + 8 * i;
       dma_piece32(rsA, st + c * 1024, c, P.lda, m0, M, k0, K, lane);
     }
-    dma_piece32(rsB, st + A_BYTES + wave * 1024, wave, P.ldb, n0, N, k0, K, lane);   // B: 8 pieces, one per wave
+    if (B_KR) dma_piece_kr(rsB, st + A_BYTES + wave * 1024, wave, P.ldb, n0, N, k0, K, lane);   // B: 8 pieces, one per wave
+    else      dma_piece32(rsB, st + A_BYTES + wave * 1024, wave, P.ldb, n0, N, k0, K, lane);
   };
 
   f32x4_t acc[4][4];
@@ -122,8 +159,20 @@ void gemm5_grouped_kernel(const GemmArgs args, const int total_tiles) {
     const char* sB = sA + A_BYTES;
     if (kt + 2 < nk) issue_tile(kt + 2);
     bf16x8_t fm[4], fn[4];
+    if (B_KR) {
+      s16x4_t nlo[4], nhi[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { fn[i] = read_frag32(sB, wn + i * 16, lane); fm[i] = read_frag32(sA, wm + i * 16, lane); }
+      for (int i = 0; i < 4; ++i) read_frag_kr32(sB, wn + i * 16, lane, nlo[i], nhi[i]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fm[i] = read_frag32(sA, wm + i * 16, lane);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fn[i] = tr_join(nlo[i], nhi[i]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { fn[i] = read_frag32(sB, wn + i * 16, lane); fm[i] = read_frag32(sA, wm + i * 16, lane); }
+    }
 #pragma unroll
     for (int tn = 0; tn < 4; ++tn)
 #pragma unroll
@@ -248,9 +297,14 @@ int mmf_gemm5_launch(const mmf_gemm_problem* problems, int num_problems, int lay
     a.p[i] = p;
   }
   a.tile_start[num_problems] = total;
-  if (layout != MMF_GEMM_NT) MMF_FAIL(MMF_E_UNSUPPORTED, "mmf_gemm5_launch: NT only");
-  if (out_f32) hipLaunchKernelGGL((gemm5_grouped_kernel<true>), dim3(total), dim3(NTHREADS), 0, s, a, total);
-  else         hipLaunchKernelGGL((gemm5_grouped_kernel<false>), dim3(total), dim3(NTHREADS), 0, s, a, total);
+  if (layout == MMF_GEMM_TN) MMF_FAIL(MMF_E_UNSUPPORTED, "mmf_gemm5_launch: NT and NN only");
+  if (layout == MMF_GEMM_NN) {
+    if (out_f32) hipLaunchKernelGGL((gemm5_grouped_kernel<true, true>), dim3(total), dim3(NTHREADS), 0, s, a, total);
+    else         hipLaunchKernelGGL((gemm5_grouped_kernel<true, false>), dim3(total), dim3(NTHREADS), 0, s, a, total);
+  } else {
+    if (out_f32) hipLaunchKernelGGL((gemm5_grouped_kernel<false, true>), dim3(total), dim3(NTHREADS), 0, s, a, total);
+    else         hipLaunchKernelGGL((gemm5_grouped_kernel<false, false>), dim3(total), dim3(NTHREADS), 0, s, a, total);
+  }
   MMF_CHECK_LAUNCH("mmf_gemm_grouped(v5)");
   return MMF_OK;
 }

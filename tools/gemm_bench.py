@@ -51,9 +51,22 @@ def main():
         ("NT ffn1 group x6", GEMM_NT, [(r, 3072, 768) for r in rows], EPI_BIAS, False),
         ("NT ffn2 group x6", GEMM_NT, [(r, 768, 3072) for r in rows], EPI_BIAS, False),
         ("NT outproj group x6", GEMM_NT, [(r, 768, 768) for r in rows], EPI_BIAS, False),
+        ("NT inproj group x12", GEMM_NT, [(r, 768, 768) for r in rows] + [(r, 1536, 768) for r in rows], EPI_BIAS, False),
+        ("NT self inproj x3", GEMM_NT, [(r, 2304, 768) for r in (8192, 6400, 480)], EPI_BIAS, False),
+        ("NT ffn1 group x3", GEMM_NT, [(r, 3072, 768) for r in (8192, 6400, 480)], EPI_BIAS, False),
+        ("NT ffn2 group x3", GEMM_NT, [(r, 768, 3072) for r in (8192, 6400, 480)], EPI_BIAS, False),
+        ("NT outproj group x3", GEMM_NT, [(r, 768, 768) for r in (8192, 6400, 480)], EPI_BIAS, False),
+        ("NT inproj group x6", GEMM_NT, [(8192, 768, 768), (6400, 1536, 768), (6400, 768, 768), (480, 1536, 768), (480, 768, 768), (8192, 1536, 768)], EPI_BIAS, False),
         ("NN 4096^3", GEMM_NN, [(4096, 4096, 4096)], 0, False),
         ("NN dH group x6", GEMM_NN, [(r, 3072, 768) for r in rows], 0, False),
         ("NN dX group x6", GEMM_NN, [(r, 768, 3072) for r in rows], 0, False),
+        ("NN outproj dgrad x6", GEMM_NN, [(r, 768, 768) for r in rows], 0, False),
+        ("NN inproj dgrad x12", GEMM_NN, [(r, 768, 768) for r in rows] + [(r, 768, 1536) for r in rows], 0, False),
+        ("NN self inproj dgrad x3", GEMM_NN, [(r, 768, 2304) for r in (8192, 6400, 480)], 0, False),
+        ("NN dH group x3", GEMM_NN, [(r, 3072, 768) for r in (8192, 6400, 480)], 0, False),
+        ("NN dX group x3", GEMM_NN, [(r, 768, 3072) for r in (8192, 6400, 480)], 0, False),
+        ("NN outproj dgrad x3", GEMM_NN, [(r, 768, 768) for r in (8192, 6400, 480)], 0, False),
+        ("NN inproj dgrad x6", GEMM_NN, [(8192, 768, 768), (6400, 768, 1536), (6400, 768, 768), (480, 768, 1536), (480, 768, 768), (8192, 768, 1536)], 0, False),
         ("TN 4096^3", GEMM_TN, [(4096, 4096, 4096)], EPI_ACCUM, True),
         ("TN dW1 group x6", GEMM_TN, [(3072, 768, r) for r in rows], EPI_ACCUM, True),
         ("TN dWo group x6", GEMM_TN, [(768, 768, r) for r in rows], EPI_ACCUM, True),
