@@ -276,9 +276,10 @@ static const int g_shortk_mode = [] { const char* e = getenv("MMF_GEMM_SHORTK");
 static const int g_shortk_nn = [] { const char* e = getenv("MMF_GEMM_SHORTK_NN"); return e ? atoi(e) : 0; }();
 // MMF_GEMM_POLICY: 1 = round 1's rule (below), 2 = round 2's rule from the per-group microbenchmarks
 // (profiles/r02_gemm_generations.txt: every MulT launch group x {256x128, 256x256, 256x128/32-deep} in isolation).
+static const int g_tn5 = [] { const char* e = getenv("MMF_GEMM_TN5"); return e ? atoi(e) : 0; }();   // wgrad on the 32-deep two-workgroups-per-CU kernel
 static const int g_policy = [] { const char* e = getenv("MMF_GEMM_POLICY"); return e ? atoi(e) : 2; }();
 static int auto_impl(const mmf_gemm_problem* p, int n, int layout) {
-  if (layout == MMF_GEMM_TN) return 2;
+  if (layout == MMF_GEMM_TN) return g_tn5 ? 5 : 2;
   long tiles = 0;
   int kmax = 0;
   for (int i = 0; i < n; ++i) {
@@ -347,7 +348,6 @@ extern "C" int mmf_gemm_grouped_ex(const mmf_gemm_problem* problems, int num_pro
   int impl = gemm_impl();
   if (impl == 0) impl = auto_impl(problems, num_problems, layout);
   if (needs_v2 && impl != 4 && impl != 5) impl = 2;   // only gemm2 / gemm4 / gemm5 have the alpha / dropout epilogue
-  if (impl == 5 && layout == MMF_GEMM_TN) impl = 2;
   t_last_impl = impl;
   GemmArgs a;
   a.nprob = num_problems;
@@ -382,10 +382,7 @@ extern "C" int mmf_gemm_grouped_ex(const mmf_gemm_problem* problems, int num_pro
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (impl == 2) return mmf_gemm2_launch(problems, num_problems, layout, epilogue, out_f32, extra, s);
   if (impl == 4) return mmf_gemm4_launch(problems, num_problems, layout, epilogue, out_f32, extra, s);
-  if (impl == 5) {
-    if (layout != MMF_GEMM_TN) return mmf_gemm5_launch(problems, num_problems, layout, epilogue, out_f32, extra, s);
-    return mmf_gemm2_launch(problems, num_problems, layout, epilogue, out_f32, extra, s);
-  }
+  if (impl == 5) return mmf_gemm5_launch(problems, num_problems, layout, epilogue, out_f32, extra, s);
 #ifdef MMF_LEGACY_KERNELS
   if (impl == 3) {
     bool wide_ok = true;              // the persistent kernel only has the 16-byte bf16 epilogue

@@ -1,4 +1,4 @@
-// Grouped bf16 GEMM, NT and (round 2) NN layouts, short-K variant: the 256 x 128 LDS-DMA ring of gemm2.hip with a 32-deep k-step
+// Grouped bf16 GEMM, NT and (round 2) NN / TN layouts, short-K variant: the 256 x 128 LDS-DMA ring of gemm2.hip with a 32-deep k-step
 // and a 72 KiB ring, so that TWO workgroups fit a CU (2 x 72 KiB LDS, <= 128 registers, 16 waves per CU).
 //
 // Why: at K = 768 a 256 x 128 tile spends ~4 us in its MFMA loop and about as long filling its pipeline and
@@ -74,8 +74,11 @@ __device__ __forceinline__ s16x4_t tr_read_asm(const char* p) {
   asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(addr));
   return r;
 }
-// transposed fragment of the 16 idx [idx0, idx0 + 16) x 32 k of a KR tile: lane l = (idx idx0 + (l & 15), k chunk l >> 4)
+// transposed fragment of the 16 idx [idx0, idx0 + 16) x 32 k of a KR tile: lane l = (idx idx0 + (l & 15), k chunk l >> 4);
+// a 256-idx tile (the TN layout's A operand) is two 128-idx halves of 8 KiB each
 __device__ __forceinline__ void read_frag_kr32(const char* tile, int idx0, int lane, s16x4_t& lo, s16x4_t& hi) {
+  tile += (idx0 >> 7) * 8192;
+  idx0 &= 127;
   const int kb = (lane >> 4) << 3;
   const int q = (lane >> 2) & 3, p = lane & 3;
   const int chunk = (idx0 >> 3) + (p >> 1);
@@ -93,7 +96,7 @@ __device__ __forceinline__ bf16x8_t read_frag32(const char* tile, int idx0, int 
   return *reinterpret_cast<const bf16x8_t*>(tile + kc32_off(idx0 + (lane & 15), lane >> 4));
 }
 
-template <bool B_KR, bool OUT_F32>
+template <bool A_KR, bool B_KR, bool OUT_F32>
 __global__ __launch_bounds__(NTHREADS, 4)      // <= 128 registers: two 8-wave workgroups per CU
 void gemm5_grouped_kernel(const GemmArgs args, const int total_tiles) {
   __shared__ __attribute__((aligned(1024))) char smem[STAGES * STAGE_BYTES];
@@ -121,7 +124,7 @@ void gemm5_grouped_kernel(const GemmArgs args, const int total_tiles) {
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
 
   // buffer descriptors (wave-uniform: built from kernel arguments only)
-  const int a_rows = M, b_rows = B_KR ? K : N;
+  const int a_rows = A_KR ? K : M, b_rows = B_KR ? K : N;
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<void*>(P.A), 0, (int)((size_t)a_rows * P.lda * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
@@ -133,7 +136,8 @@ void gemm5_grouped_kernel(const GemmArgs args, const int total_tiles) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {                   // A: 16 pieces, two per wave
       const int c = wave + 8 * i;
-      dma_piece32(rsA, st + c * 1024, c, P.lda, m0, M, k0, K, lane);
+      if (A_KR) dma_piece_kr(rsA, st + c * 1024, c & 7, P.lda, m0 + 128 * (c >> 3), M, k0, K, lane);   // half c >> 3
+      else      dma_piece32(rsA, st + c * 1024, c, P.lda, m0, M, k0, K, lane);
     }
     if (B_KR) dma_piece_kr(rsB, st + A_BYTES + wave * 1024, wave, P.ldb, n0, N, k0, K, lane);   // B: 8 pieces, one per wave
     else      dma_piece32(rsB, st + A_BYTES + wave * 1024, wave, P.ldb, n0, N, k0, K, lane);
@@ -144,6 +148,14 @@ void gemm5_grouped_kernel(const GemmArgs args, const int total_tiles) {
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // fused bias gradient (wgrad): column sums of A via an all-ones n-fragment (gemm2.hip)
+  const bool do_colsum = A_KR && (args.epi & MMF_EPI_COLSUM_A) && n0 == 0 && wn == 0;
+  f32x4_t csum[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) csum[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const s16x8_t ones_s = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
+  const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones_s);
 
   const int nk = (K + BK - 1) / BK;
   issue_tile(0);
@@ -159,7 +171,21 @@ void gemm5_grouped_kernel(const GemmArgs args, const int total_tiles) {
     const char* sB = sA + A_BYTES;
     if (kt + 2 < nk) issue_tile(kt + 2);
     bf16x8_t fm[4], fn[4];
-    if (B_KR) {
+    if (A_KR) {                                     // TN: both operands transposed; two batches share the temporaries
+      s16x4_t lo[4], hi[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) read_frag_kr32(sB, wn + i * 16, lane, lo[i], hi[i]);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fn[i] = tr_join(lo[i], hi[i]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) read_frag_kr32(sA, wm + i * 16, lane, lo[i], hi[i]);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fm[i] = tr_join(lo[i], hi[i]);
+    } else if (B_KR) {
       s16x4_t nlo[4], nhi[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) read_frag_kr32(sB, wn + i * 16, lane, nlo[i], nhi[i]);
@@ -178,6 +204,17 @@ void gemm5_grouped_kernel(const GemmArgs args, const int total_tiles) {
 #pragma unroll
       for (int tm = 0; tm < 4; ++tm)
         acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fn[tn], fm[tm], acc[tn][tm], 0, 0, 0);
+    if (A_KR && do_colsum) {
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm) csum[tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fm[tm], csum[tm], 0, 0, 0);
+    }
+  }
+  if (A_KR && do_colsum && lane < 16) {          // every MFMA row holds the same sums: take row 0 (lanes 0..15, reg 0)
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm) {
+      const int m = m0 + wm + tm * 16 + lane;
+      if (m < M) atomicAdd(const_cast<float*>(P.bias) + m, csum[tm][0]);
+    }
   }
 
   // ---- epilogue: lane owns C[m][n..n+3] for each of its 16 MFMA tiles -------------------------------
@@ -297,13 +334,15 @@ int mmf_gemm5_launch(const mmf_gemm_problem* problems, int num_problems, int lay
     a.p[i] = p;
   }
   a.tile_start[num_problems] = total;
-  if (layout == MMF_GEMM_TN) MMF_FAIL(MMF_E_UNSUPPORTED, "mmf_gemm5_launch: NT and NN only");
-  if (layout == MMF_GEMM_NN) {
-    if (out_f32) hipLaunchKernelGGL((gemm5_grouped_kernel<true, true>), dim3(total), dim3(NTHREADS), 0, s, a, total);
-    else         hipLaunchKernelGGL((gemm5_grouped_kernel<true, false>), dim3(total), dim3(NTHREADS), 0, s, a, total);
+  if (layout == MMF_GEMM_TN) {
+    if (out_f32) hipLaunchKernelGGL((gemm5_grouped_kernel<true, true, true>), dim3(total), dim3(NTHREADS), 0, s, a, total);
+    else         hipLaunchKernelGGL((gemm5_grouped_kernel<true, true, false>), dim3(total), dim3(NTHREADS), 0, s, a, total);
+  } else if (layout == MMF_GEMM_NN) {
+    if (out_f32) hipLaunchKernelGGL((gemm5_grouped_kernel<false, true, true>), dim3(total), dim3(NTHREADS), 0, s, a, total);
+    else         hipLaunchKernelGGL((gemm5_grouped_kernel<false, true, false>), dim3(total), dim3(NTHREADS), 0, s, a, total);
   } else {
-    if (out_f32) hipLaunchKernelGGL((gemm5_grouped_kernel<false, true>), dim3(total), dim3(NTHREADS), 0, s, a, total);
-    else         hipLaunchKernelGGL((gemm5_grouped_kernel<false, false>), dim3(total), dim3(NTHREADS), 0, s, a, total);
+    if (out_f32) hipLaunchKernelGGL((gemm5_grouped_kernel<false, false, true>), dim3(total), dim3(NTHREADS), 0, s, a, total);
+    else         hipLaunchKernelGGL((gemm5_grouped_kernel<false, false, false>), dim3(total), dim3(NTHREADS), 0, s, a, total);
   }
   MMF_CHECK_LAUNCH("mmf_gemm_grouped(v5)");
   return MMF_OK;

@@ -121,7 +121,7 @@ def test_gemm_grouped_and_strided():
     assert float(out[:, 264:].float().abs().max()) == 0.0 and float(out[100:, 64:264].float().abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("layout,impl", [(GEMM_TN, 2), (GEMM_NT, 2), (GEMM_NT, 4), (GEMM_NT, 5), (GEMM_NN, 2), (GEMM_NN, 4), (GEMM_NN, 5)])
+@pytest.mark.parametrize("layout,impl", [(GEMM_TN, 2), (GEMM_TN, 5), (GEMM_NT, 2), (GEMM_NT, 4), (GEMM_NT, 5), (GEMM_NN, 2), (GEMM_NN, 4), (GEMM_NN, 5)])
 def test_gemm_grouped_many_tiles_mixed_k(layout, impl):
     """A grouped launch big enough for the granule tile -> XCD map (mmf_xcd_tile: >= 8 x 32 tiles handed out in
     32-tile granules, the remainder as one range per XCD) with the maximum problem count and K from 16 to 2048, as in
