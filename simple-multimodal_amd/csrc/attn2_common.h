@@ -33,6 +33,7 @@ struct AttnArgs2 {
   unsigned drop_thresh, site;
   float inv_keep;
   const unsigned long long* rng_state;
+  int split;      // sweep split of the <= 32-row problems in the backward kernels (MMF_ATTN_SPLIT=0: off)
   int debug;      // timing ablations (MMF_ATTN2_DEBUG, results wrong by design): 1 no K/V DMA after tile 0, 2 no compute
   int blk_start[MMF_ATTN_MAX_PROBLEMS + 1];   // multiples of 8 (XCD alignment)
   int nwg[MMF_ATTN_MAX_PROBLEMS];             // real workgroups of the problem = B*H*nchunk
@@ -130,6 +131,8 @@ int fill_args2(AttnArgs2& a, const mmf_attn_problem* problems, int n, float scal
   a.rng_state = reinterpret_cast<const unsigned long long*>(rng_state);
   const char* dbg = getenv("MMF_ATTN2_DEBUG");
   a.debug = dbg ? atoi(dbg) : 0;
+  static const int split = [] { const char* e = getenv("MMF_ATTN_SPLIT"); return e ? atoi(e) : 1; }();
+  a.split = split;
   int order[MMF_ATTN_MAX_PROBLEMS];
   for (int i = 0; i < n; ++i) order[i] = i;
   // Launch order = longest per-workgroup chain first: a workgroup's duration is set by the length of its sweep
