@@ -201,6 +201,30 @@ void attn_fwd2_kernel(const AttnArgs2 a) {
 }
 
 
+// Default since round 2 (MMF_ATTN_FWD_ROWS=256 selects the two-blocks-per-wave kernel above): one 32-row query block per wave (128 rows per workgroup), <= 168 registers, so
+// THREE workgroups share a CU (3 x 52 KiB of LDS) and a wave's LDS / MFMA dependency waits have two other waves on
+// its SIMD to hide under; the price is twice the K/V fragment reads and DMA per query row.
+template <int DH, bool DROP>
+__global__ __launch_bounds__(NT, 3)
+void attn_fwd2n_kernel(const AttnArgs2 a) {
+  constexpr int STAGE_B = 2 * 64 * (DH + 8) * 2;
+  __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE_B];
+  const int bid = blockIdx.x;
+  int pi = 0;
+  while (pi + 1 < a.nprob && bid >= a.blk_start[pi + 1]) ++pi;
+  const int loc = bid - a.blk_start[pi], n8 = (a.blk_start[pi + 1] - a.blk_start[pi]) >> 3;
+  const int item = (loc & 7) * n8 + (loc >> 3);
+  if (item >= a.nwg[pi]) return;
+  const mmf_attn_problem& P = a.p[pi];
+  const int nchunk = a.nchunk[pi], rpc = a.rpc[pi];         // rpc <= 128 here
+  const int bh = item / nchunk, q0 = (item % nchunk) * rpc;
+  const int nb = (min(P.Tq, q0 + rpc) - q0 + 31) >> 5;      // 32-row query blocks in this chunk (1..4)
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int qs = q0 + 32 * wave, pidx = a.orig[pi];
+  if (wave < nb) fwd2_wave<DH, DROP, 1, 2>(a, P, pidx, bh, qs, smem);
+  else           fwd2_wave<DH, DROP, 0, 2>(a, P, pidx, bh, qs, smem);
+}
+
 // ================================================================================================
 // backward, second generation.  Same arithmetic as attention.hip's two kernels (dQ + delta, then dK/dV; recompute
 // from LSE; no atomics, deterministic); what changes is how the swept tiles reach the MFMAs:
@@ -567,10 +591,19 @@ int mmf_attn_fwd2_launch_indexed(const mmf_attn_problem* problems, const int* id
                                  float drop_p, const uint64_t* rng_state, uint32_t site, hipStream_t s) {
   if (int rc = check_ranges("mmf_attn_fwd_grouped", problems, n)) return rc;
   AttnArgs2 a;
-  const int total = fill_args2(a, problems, n, scale, drop_p, rng_state, site, 256, false, true);
+  static const int rows = [] { const char* e = getenv("MMF_ATTN_FWD_ROWS"); return (e && atoi(e) == 256) ? 256 : 128; }();   // 128 (round 2): see attn_fwd2n_kernel
+  const int total = fill_args2(a, problems, n, scale, drop_p, rng_state, site, rows, false, true);
   if (idx)
     for (int k = 0; k < n; ++k) a.orig[k] = (short)idx[a.orig[k]];
   const bool dr = a.drop_thresh != 0u;
+  if (rows == 128) {
+    if (head_dim == 96) { if (dr) hipLaunchKernelGGL((attn_fwd2n_kernel<96, true>), dim3(total), dim3(NT), 0, s, a);
+                          else    hipLaunchKernelGGL((attn_fwd2n_kernel<96, false>), dim3(total), dim3(NT), 0, s, a); }
+    else                { if (dr) hipLaunchKernelGGL((attn_fwd2n_kernel<64, true>), dim3(total), dim3(NT), 0, s, a);
+                          else    hipLaunchKernelGGL((attn_fwd2n_kernel<64, false>), dim3(total), dim3(NT), 0, s, a); }
+    MMF_CHECK_LAUNCH("mmf_attn_fwd_grouped(v2n)");
+    return MMF_OK;
+  }
   static const int stages = [] { const char* e = getenv("MMF_ATTN_FWD_STAGES"); const int v = e ? atoi(e) : 2; return v == 3 ? 3 : 2; }();   // 3 measured equal (round 2): the per-tile chain, not the DMA, is what a workgroup waits for
   if (stages == 3) {
     if (head_dim == 96) { if (dr) hipLaunchKernelGGL((attn_fwd2_kernel<96, true, 3>), dim3(total), dim3(NT), 0, s, a);
