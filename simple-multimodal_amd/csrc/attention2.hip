@@ -239,14 +239,13 @@ void attn_fwd2n_kernel(const AttnArgs2 a) {
 // ================================================================================================
 
 // dQ^T += K^T . dS^T for block KT: PvStep with the K tile as the transposed operand.
-// MODE 0: the wave only stages tiles and joins the barriers; 1: it owns the 32 query rows at qs; 2 (round 2, "sweep split"):
-// the problem has <= 32 query rows (the x30 problems: one 32-row block, a chain of Tk / 64 tiles), so waves 0 and 1 BOTH
-// take those rows and wave w works on 32-key block w of every tile — half the chain per wave; wave 1's partial dQ^T
-// is added to wave 0's through LDS at the end (split_wg tells the staging-only waves to join that barrier).
-template <int DH, bool DROP, int MODE>
+// ACTIVE false: the wave only stages tiles and joins the barriers.  (The sweep split of the dK/dV kernel below was tried here
+// too — waves 0 and 1 sharing the 32 query rows of a x30 problem — and taken out again: at this kernel's 168-register budget
+// (three waves per SIMD) a third instantiation of the body spilled 31 registers instead of 6, a runtime selector 66, and the
+// spills land in the main path's loop.)
+template <int DH, bool DROP, bool ACTIVE>
 __device__ __forceinline__ void dq2_wave(const AttnArgs2& a, const mmf_attn_problem& P, const int pidx, const int bh,
-                                         const int qs, char* smem, const bool split_wg) {
-  constexpr bool ACTIVE = MODE != 0;
+                                         const int qs, char* smem) {
   constexpr int KS = DH / 16, DT = DH / 32, SB = (DH + 8) * 2, TILE_B = 64 * SB, STAGE_B = 2 * TILE_B;
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -277,7 +276,7 @@ __device__ __forceinline__ void dq2_wave(const AttnArgs2& a, const mmf_attn_prob
       for (int e = 0; e < 4; ++e) delta += bf16lo(x[e]) * bf16lo(y[e]) + bf16hi(x[e]) * bf16hi(y[e]);
     }
     delta = half_sum(delta);
-    if (half == 0 && qrow < Tq && !(MODE == 2 && wave != 0)) P.delta[(size_t)bh * Tq + qrow] = delta;
+    if (half == 0 && qrow < Tq) P.delta[(size_t)bh * Tq + qrow] = delta;
     lse2 = (qrow < Tq ? P.LSE[(size_t)bh * Tq + qrow] : 0.f) * LOG2E;
   }
   const float c = a.scale * LOG2E;
@@ -304,7 +303,6 @@ __device__ __forceinline__ void dq2_wave(const AttnArgs2& a, const mmf_attn_prob
         constexpr int KT = decltype(KTc)::value;
         const int k0 = j * 64 + 32 * KT;
         if (k0 >= Tk) return;
-        if (MODE == 2 && KT != wave) return;               // sweep split: this wave's half of the tile
         f32x16_t s, dp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
@@ -335,25 +333,7 @@ __device__ __forceinline__ void dq2_wave(const AttnArgs2& a, const mmf_attn_prob
       block(std::integral_constant<int, 1>{});
     }
   }
-  if (split_wg) {                                        // wave 1's partial sums -> wave 0 (the free stage holds them)
-    float* red = reinterpret_cast<float*>(smem + (ntiles & 1) * STAGE_B);
-    if (MODE == 2 && wave == 1) {
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) red[(dt * 16 + r) * 64 + lane] = dq[0][dt][r];
-    }
-    __syncthreads();
-    if (MODE == 2 && wave == 0) {
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dq[0][dt][r] += red[(dt * 16 + r) * 64 + lane];
-    }
-    __syncthreads();                                     // the store below reuses that memory
-  }
   if constexpr (ACTIVE) {
-    if (MODE == 2 && wave != 0) return;
     char* oslice = smem + (ntiles & 1) * STAGE_B + wave * (32 * SB);
     store_rows_lds<DH>(dq[0], a.scale, static_cast<unsigned short*>(P.dQ) + qoff, P.ldq, qs, Tq, lane, oslice);
   }
@@ -375,12 +355,8 @@ void attn_bwd_dq2_kernel(const AttnArgs2 a) {
   const int bh = item / nchunk, q0 = (item % nchunk) * 128;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int qs = q0 + 32 * wave, pidx = a.orig[pi];
-  const bool split = a.split && P.Tq <= 32;                 // workgroup-uniform
-  if (split) {
-    if (wave < 2) dq2_wave<DH, DROP, 2>(a, P, pidx, bh, q0, smem, true);
-    else          dq2_wave<DH, DROP, 0>(a, P, pidx, bh, qs, smem, true);
-  } else if (qs < P.Tq) dq2_wave<DH, DROP, 1>(a, P, pidx, bh, qs, smem, false);
-  else                  dq2_wave<DH, DROP, 0>(a, P, pidx, bh, qs, smem, false);
+  if (qs < P.Tq) dq2_wave<DH, DROP, true>(a, P, pidx, bh, qs, smem);
+  else           dq2_wave<DH, DROP, false>(a, P, pidx, bh, qs, smem);
 }
 
 // dV^T += dO^T . P and dK^T += Q^T . dS for the 32 query rows of block QS: 4 DT fragment steps alternating the
@@ -408,12 +384,11 @@ struct DkvStep {
   }
 };
 
-// MODE as in dq2_wave; 2: the problem has <= 32 keys, waves 0 and 1 both own them and wave w works on 32-row query
+// Sweep split as in dq2_wave: a problem with <= 32 keys gives them to waves 0 and 1, wave w works on 32-row query
 // block w of every tile; wave 1's partial dK^T, dV^T are added to wave 0's through LDS at the end.
-template <int DH, bool DROP, int MODE>
+template <int DH, bool DROP, bool ACTIVE>
 __device__ __forceinline__ void dkv2_wave(const AttnArgs2& a, const mmf_attn_problem& P, const int pidx, const int bh,
-                                          const int k0, char* smem, const bool split_wg) {
-  constexpr bool ACTIVE = MODE != 0;
+                                          const int k0, char* smem, const bool split_wg, const int sel) {
   constexpr int KS = DH / 16, DT = DH / 32, SB = (DH + 8) * 2, TILE_B = 64 * SB, STAGE_B = 2 * TILE_B;
   constexpr int STAT_OFF = 2 * STAGE_B;                      // [stage][lse 64 | delta 64] f32 behind the two stages
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
@@ -469,7 +444,7 @@ __device__ __forceinline__ void dkv2_wave(const AttnArgs2& a, const mmf_attn_pro
         constexpr int QS = decltype(QSc)::value;
         const int q0 = j * 64 + 32 * QS;
         if (q0 >= Tq) return;
-        if (MODE == 2 && QS != wave) return;               // sweep split: this wave's half of the tile
+        if (sel >= 0 && QS != sel) return;                 // sweep split: this wave's half of the tile
         f32x16_t s, dp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
@@ -510,7 +485,7 @@ __device__ __forceinline__ void dkv2_wave(const AttnArgs2& a, const mmf_attn_pro
   }
   if (split_wg) {                                        // wave 1's partial sums -> wave 0 (the free stage holds them)
     float* red = reinterpret_cast<float*>(smem + (ntiles & 1) * STAGE_B);
-    if (MODE == 2 && wave == 1) {
+    if (ACTIVE && sel == 1) {
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -520,7 +495,7 @@ __device__ __forceinline__ void dkv2_wave(const AttnArgs2& a, const mmf_attn_pro
         }
     }
     __syncthreads();
-    if (MODE == 2 && wave == 0) {
+    if (ACTIVE && sel == 0) {
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -532,7 +507,7 @@ __device__ __forceinline__ void dkv2_wave(const AttnArgs2& a, const mmf_attn_pro
     __syncthreads();
   }
   if constexpr (ACTIVE) {
-    if (MODE == 2 && wave != 0) return;
+    if (sel > 0) return;
     char* oslice = smem + (ntiles & 1) * STAGE_B + wave * (32 * SB);
     store_rows_lds<DH>(dk, a.scale, static_cast<unsigned short*>(P.dK) + koff, P.ldk, k0, Tk, lane, oslice);
     store_rows_lds<DH>(dv, 1.f, static_cast<unsigned short*>(P.dV) + voff, P.ldv, k0, Tk, lane, oslice);
@@ -556,11 +531,9 @@ void attn_bwd_dkv2_kernel(const AttnArgs2 a) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int k0 = kc0 + 32 * wave, pidx = a.orig[pi];
   const bool split = a.split && P.Tk <= 32;                 // workgroup-uniform
-  if (split) {
-    if (wave < 2) dkv2_wave<DH, DROP, 2>(a, P, pidx, bh, kc0, smem, true);
-    else          dkv2_wave<DH, DROP, 0>(a, P, pidx, bh, k0, smem, true);
-  } else if (k0 < P.Tk) dkv2_wave<DH, DROP, 1>(a, P, pidx, bh, k0, smem, false);
-  else                  dkv2_wave<DH, DROP, 0>(a, P, pidx, bh, k0, smem, false);
+  const bool act = split ? wave < 2 : k0 < P.Tk;
+  if (act) dkv2_wave<DH, DROP, true>(a, P, pidx, bh, split ? kc0 : k0, smem, split, split ? wave : -1);
+  else     dkv2_wave<DH, DROP, false>(a, P, pidx, bh, k0, smem, split, -1);
 }
 
 }  // namespace
