@@ -208,13 +208,14 @@ def cpu_baseline(workload):
 
 _SYMBOL = {"gemm4_grouped_kernel<NT,bf16>": ["gemm4_grouped_kernel<false, false, false>"],
            "gemm2_grouped_kernel<NT,bf16>": ["gemm2_grouped_kernel<false, false, false>"],
-           "gemm5_grouped_kernel<NT,bf16>": ["gemm5_grouped_kernel<false>"],
+           "gemm5_grouped_kernel<NT,bf16>": ["gemm5_grouped_kernel<false, false, false>", "gemm5_grouped_kernel<false>"],
            "gemm2_grouped_kernel<NT,f32>": ["gemm2_grouped_kernel<false, false, true>"],
-           "gemm5_grouped_kernel<NT,f32>": ["gemm5_grouped_kernel<true>"],
+           "gemm5_grouped_kernel<NT,f32>": ["gemm5_grouped_kernel<false, false, true>", "gemm5_grouped_kernel<true>"],
            "gemm4_grouped_kernel<NN,bf16>": ["gemm4_grouped_kernel<false, true, false>"],
            "gemm2_grouped_kernel<NN,bf16>": ["gemm2_grouped_kernel<false, true, false>"],
+           "gemm5_grouped_kernel<NN,bf16>": ["gemm5_grouped_kernel<false, true, false>"],
            "gemm2_grouped_kernel<TN,f32>": ["gemm2_grouped_kernel<true, true, true>"],
-           "attn_fwd_kernel<96>": ["attn_fwd2_kernel<96, false>"],
+           "attn_fwd_kernel<96>": ["attn_fwd2n_kernel<96, false>", "attn_fwd2_kernel<96, false, 2>", "attn_fwd2_kernel<96, false>"],
            "attn_bwd_kernels<96>": ["attn_bwd_dq2_kernel<96, false>", "attn_bwd_dkv2_kernel<96, false>"]}
 
 
@@ -598,7 +599,7 @@ def main():
         sec = af["ms_total"] * 1e-3
         traffic, util, pmc_src = pmc_lookup("attn_fwd_kernel<96>")
         line["roofline_attention_fwd"] = {
-            "kernel": "attn_fwd2_kernel<96> (all nine MulT attention cores, 2 launches)",
+            "kernel": "attn_fwd2n_kernel<96> (all nine MulT attention cores, 2 launches)",
             "mfma": {"achieved": round(af["flops_total"] / sec / 1e12, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(af["flops_total"] / sec / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4)},
             "hbm": {"achieved": round(af["bytes_total"] / sec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
