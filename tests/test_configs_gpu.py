@@ -344,3 +344,52 @@ def test_modality_dropout_statistics():
     # eval: identity, same objects
     o = md(t, a, v, training=False)
     assert o[0] is t and o[1] is a and o[2] is v
+
+
+# ------------------------------------------------------------------------------------------------------------
+# edge cases of the boundary: batch of one, sequence of one, empty batch, unsupported widths
+# ------------------------------------------------------------------------------------------------------------
+def _mult(d=192, H=2):
+    import config as cfgmod
+    from models import fusion_layers as fl
+    cfg = cfgmod.ModelConfig()
+    cfg.fusion_hidden_size, cfg.fusion_num_heads, cfg.fusion_dropout = d, H, 0.0
+    torch.manual_seed(1)
+    return cfg, fl.MultimodalTransformer(cfg)
+
+
+@pytest.mark.parametrize("B,Ts", [(1, (1, 1, 1)), (1, (65, 3, 1)), (2, (1, 130, 7))])
+def test_mult_smallest_shapes_match_oracle(B, Ts):
+    """Batch of one, sequences of one token (softmax over one key), a modality far longer than the others."""
+    cfg, m = _mult()
+    P = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    xs = synth.make_features(B, Ts, 192, seed=5)
+    xr = [x.clone().requires_grad_(True) for x in xs]
+    with ref_cpu.bf16_storage():
+        ref = ref_cpu.multimodal_transformer(P, "", *xr, 2)
+        synth.probe_loss(ref).backward()
+    m = m.cuda().eval()
+    xg = [x.cuda().requires_grad_(True) for x in xs]
+    out = m(*xg)
+    synth.probe_loss(out).backward()
+    torch.cuda.synchronize()
+    for k, want in ref.items():
+        assert l2_rel(out[k], want.detach()) <= 5e-3, f"{k}: {l2_rel(out[k], want.detach()):.3e}"
+    for g, r in zip(xg, xr):
+        assert l2_rel(g.grad, r.grad) <= 2e-2, f"input grad {l2_rel(g.grad, r.grad):.3e}"
+
+
+def test_empty_batch_and_bad_widths_raise_cleanly():
+    """An empty batch or a feature width the kernels cannot take must come back as a Python exception from the
+    C ABI's validation (no launch with an empty grid, no fault), and the module must stay usable afterwards."""
+    cfg, m = _mult()
+    m = m.cuda().eval()
+    with pytest.raises((RuntimeError, ValueError)):
+        m(torch.zeros(0, 4, 192, device="cuda"), torch.zeros(0, 3, 192, device="cuda"), torch.zeros(0, 2, 192, device="cuda"))
+    with pytest.raises((RuntimeError, ValueError)):                 # feature width differs from the module's
+        m(torch.zeros(2, 4, 190, device="cuda"), torch.zeros(2, 3, 190, device="cuda"), torch.zeros(2, 2, 190, device="cuda"))
+    with pytest.raises(RuntimeError):                               # CPU tensors: there is no fallback
+        m(torch.zeros(2, 4, 192), torch.zeros(2, 3, 192), torch.zeros(2, 2, 192))
+    out = m(torch.randn(2, 4, 192, device="cuda"), torch.randn(2, 3, 192, device="cuda"), torch.randn(2, 2, 192, device="cuda"))
+    torch.cuda.synchronize()
+    assert out["fused_features"].shape == (2, 192) and bool(torch.isfinite(out["fused_features"]).all())
