@@ -18,6 +18,12 @@ CASES = {
                           B=3, Ts=(70, 40, 6)),
     "mult_seq_dh64": dict(cls="MultimodalTransformer", cfg=dict(fusion_hidden_size=128, fusion_num_heads=2),
                           B=2, Ts=(33, 65, 5)),
+    # several 128-row query tiles and many 32-key blocks per head (the online-softmax path of the kernels), ragged tails
+    "mult_seq_long": dict(cls="MultimodalTransformer", cfg=dict(fusion_hidden_size=192, fusion_num_heads=2),
+                          B=2, Ts=(300, 130, 30)),
+    # the BASELINE width and head count (d=768, 8 heads of 96) at short lengths
+    "mult_seq_d768": dict(cls="MultimodalTransformer", cfg=dict(fusion_hidden_size=768, fusion_num_heads=8),
+                          B=2, Ts=(40, 24, 6)),
     # MulT as wired by the reference model: pooled (B,d) features, T = 1
     "mult_2d": dict(cls="MultimodalTransformer", cfg=dict(fusion_hidden_size=192, fusion_num_heads=2),
                     B=4, Ts=(0, 0, 0)),
