@@ -101,16 +101,29 @@ __device__ __forceinline__ void fwd2_wave(const AttnArgs2& a, const mmf_attn_pro
 #pragma unroll
           for (int r = 0; r < 16; ++r) s[qb][r] = 0.f;
         mfma_prio(1);
+        if constexpr (NQ == 1) {
+          // all KS fragment reads in flight before the first MFMA: one exposed LDS latency per block instead of KS / 2
+          bf16x8_t kf[KS];
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          const bf16x8_t kf = row_frag<DH>(sK, 32 * KT, ks, lane);
+          for (int ks = 0; ks < KS; ++ks) kf[ks] = row_frag<DH>(sK, 32 * KT, ks, lane);
+          __builtin_amdgcn_sched_barrier(0);               // (the scheduler otherwise re-pairs them with the MFMAs)
 #pragma unroll
-          for (int qb = 0; qb < NQ; ++qb)
-            s[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qb][ks], s[qb], 0, 0, 0);
+          for (int ks = 0; ks < KS; ++ks)
+            s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[0][ks], s[0], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);               // the asm V^T reads below are invisible to the compiler's lgkmcnt count
+        } else {
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8_t kf = row_frag<DH>(sK, 32 * KT, ks, lane);
+#pragma unroll
+            for (int qb = 0; qb < NQ; ++qb)
+              s[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qb][ks], s[qb], 0, 0, 0);
+          }
         }
         mfma_prio(0);
-        s16x4_t lo, hi;
-        tr_issue<DH, 2 * KT, 0>(va, lo, hi);               // first V^T fragment lands under the softmax
+        s16x4_t lo, hi, lo1, hi1;
+        tr_issue<DH, 2 * KT, 0>(va, lo, hi);               // the first two V^T fragments land under the softmax
+        tr_issue<DH, 2 * KT + 1 / DT, 1 % DT>(va, lo1, hi1);
         const bool ragged = k0 + 32 > Tk;
 #pragma unroll
         for (int qb = 0; qb < NQ; ++qb) {
@@ -154,7 +167,7 @@ __device__ __forceinline__ void fwd2_wave(const AttnArgs2& a, const mmf_attn_pro
           }
         }
         bf16x8_t pf[NQ];
-        PvStep<DH, NQ, KT, 0>::run(va, lo, hi, s, pf, o);
+        PvStep2<DH, NQ, KT, 0>::run(va, lo, hi, lo1, hi1, s, pf, o);
       };
       block(std::integral_constant<int, 0>{});
       block(std::integral_constant<int, 1>{});

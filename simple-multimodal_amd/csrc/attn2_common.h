@@ -94,6 +94,31 @@ struct PvStep {
   }
 };
 
+// The same with the transposed reads TWO fragments ahead (fragments N and N + 1 arrive in flight, N + 2 is issued here):
+// an MFMA (32 cycles) is shorter than an LDS round trip, so one fragment of read-ahead leaves most of every read exposed
+// whenever the wave has its SIMD to itself (the 30-row problems, partly filled launches).
+template <int DH, int NQ, int KT, int N>
+struct PvStep2 {
+  static constexpr int DT = DH / 32, NF = 2 * DT;
+  static __device__ __forceinline__ void run(unsigned va, s16x4_t lo, s16x4_t hi, s16x4_t lo1, s16x4_t hi1,
+                                             const f32x16_t (&s)[NQ], bf16x8_t (&pf)[NQ], f32x16_t (&o)[NQ][DT]) {
+    s16x4_t lo2, hi2;
+    if constexpr (N + 2 < NF) tr_issue<DH, 2 * KT + (N + 2) / DT, (N + 2) % DT>(va, lo2, hi2);
+    tr_wait<(N + 2 < NF) ? 4 : (N + 1 < NF) ? 2 : 0>(lo, hi);
+    if constexpr (N == 0) mfma_prio(1);
+    const bf16x8_t vf = join(lo, hi);
+    if constexpr (N % DT == 0) {
+#pragma unroll
+      for (int qb = 0; qb < NQ; ++qb) pf[qb] = acc_frag(s[qb], N / DT);
+    }
+#pragma unroll
+    for (int qb = 0; qb < NQ; ++qb)
+      o[qb][N % DT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[qb], o[qb][N % DT], 0, 0, 0);
+    if constexpr (N + 1 < NF) PvStep2<DH, NQ, KT, N + 1>::run(va, lo1, hi1, lo2, hi2, s, pf, o);
+    else mfma_prio(0);
+  }
+};
+
 // LDS-DMA of one stage = two [64][DH+8] tiles X (at st) and Y (at st + TILE_B) of rows [64 j, 64 j + 64) of two
 // (T, ld) matrices given as buffer descriptors whose range ends after row T-1 (rows past T read as zeros).
 // Piece p = wave + 4 i covers image chunks 64 pc .. 64 pc + 63 of X (p < PIECES) or Y; chunk c is row c / CPR,

@@ -33,6 +33,17 @@ constexpr int STAGE_BYTES = A_BYTES + B_BYTES;  // 64 KiB
 constexpr int STAGES = 2;
 constexpr unsigned OOB = 0x80000000u;
 
+// MMF_GEMM_STAMPS (build-time, measurement only: `make EXTRA=-DMMF_GEMM_STAMPS`, tools/gemm_stamps.py): every wave sums
+// the s_memtime cycles it spends in each segment of the k-loop and writes the eight sums at the end; with `nomem` the
+// buffer ranges are empty, so every LDS-DMA piece returns zeros without touching L2 / HBM.
+#ifdef MMF_GEMM_STAMPS
+__device__ unsigned long long* g_stamps = nullptr;        // [workgroup][8 waves][8 segments]
+__device__ int g_stamps_nomem = 0;
+#define STAMP(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); seg[i] += t_ - tlast; tlast = t_; } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#endif
+
 struct GemmArgs {
   int nprob;
   int epi;
@@ -135,10 +146,15 @@ void gemm4_grouped_kernel(const GemmArgs args, const int total_tiles) {
 
   // buffer descriptors (wave-uniform: built from kernel arguments only)
   const int a_rows = A_KR ? K : M, b_rows = B_KR ? K : N;
+#ifdef MMF_GEMM_STAMPS
+  const int nomem_scale = g_stamps_nomem ? 0 : 1;
+#else
+  constexpr int nomem_scale = 1;
+#endif
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<void*>(P.A), 0, (int)((size_t)a_rows * P.lda * 2), 0x00020000);
+      const_cast<void*>(P.A), 0, nomem_scale * (int)((size_t)a_rows * P.lda * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<void*>(P.B), 0, (int)((size_t)b_rows * P.ldb * 2), 0x00020000);
+      const_cast<void*>(P.B), 0, nomem_scale * (int)((size_t)b_rows * P.ldb * 2), 0x00020000);
 
   auto issue_tile = [&](int kt) {
     char* st = smem + (kt % STAGES) * STAGE_BYTES;
@@ -170,13 +186,20 @@ void gemm4_grouped_kernel(const GemmArgs args, const int total_tiles) {
   const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones_s);
 
   const int nk = (K + BK - 1) / BK;
+#ifdef MMF_GEMM_STAMPS
+  unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tlast = __builtin_readcyclecounter();
+#endif
   issue_tile(0);
+  STAMP(6);
 
   for (int kt = 0; kt < nk; ++kt) {
     // 2-stage ring, prefetch distance one tile: only tile kt's loads are outstanding here
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP(0);
     __builtin_amdgcn_s_barrier();                  // every wave's pieces landed; the other stage is free
     asm volatile("" ::: "memory");
+    STAMP(1);
 
     const char* sA = smem + (kt % STAGES) * STAGE_BYTES;
     const char* sB = sA + A_BYTES;
@@ -223,9 +246,13 @@ void gemm4_grouped_kernel(const GemmArgs args, const int total_tiles) {
     // role split between the two waves of a SIMD (waves w and w+4), see gemm2.hip
     const bool want_prefetch = kt + 1 < nk;
     if (want_prefetch && wave < 4) issue_tile(kt + 1);
+    STAMP(2);
     compute(0);
+    STAMP(3);
     if (want_prefetch && wave >= 4) issue_tile(kt + 1);
+    STAMP(4);
     compute(1);
+    STAMP(5);
   }
 
   if (A_KR && do_colsum) {              // every MFMA row holds the same sums: take row 0 (lanes 0..15, reg 0)
@@ -327,6 +354,13 @@ void gemm4_grouped_kernel(const GemmArgs args, const int total_tiles) {
       }
     }
   }
+#ifdef MMF_GEMM_STAMPS
+  STAMP(7);
+  if (g_stamps && lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) g_stamps[((size_t)blockIdx.x * 8 + wave) * 8 + i] = seg[i];
+  }
+#endif
 }
 
 template <bool A_KR, bool B_KR>
@@ -336,6 +370,13 @@ void launch(const GemmArgs& a, int total, int out_f32, hipStream_t s) {
 }
 
 }  // namespace
+
+#ifdef MMF_GEMM_STAMPS
+extern "C" int mmf_debug_gemm4_stamps(unsigned long long* buf, int nomem) {
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamps_nomem), &nomem, sizeof(nomem)) != hipSuccess) return 1;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &buf, sizeof(buf)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 // called by mmf_gemm_grouped (gemm.hip) after validation
 int mmf_gemm4_launch(const mmf_gemm_problem* problems, int num_problems, int layout, int epilogue,
