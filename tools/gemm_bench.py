@@ -70,7 +70,12 @@ def main():
         ("TN 4096^3", GEMM_TN, [(4096, 4096, 4096)], EPI_ACCUM, True),
         ("TN dW1 group x6", GEMM_TN, [(3072, 768, r) for r in rows], EPI_ACCUM, True),
         ("TN dWo group x6", GEMM_TN, [(768, 768, r) for r in rows], EPI_ACCUM, True),
+        # every weight gradient of the six cross blocks, as the deferred launch holds them (q rows, kv rows per block)
+        ("TN cross blocks x30", GEMM_TN, [s for q, kv in ((8192, 6400), (8192, 480), (6400, 8192), (6400, 480), (480, 8192), (480, 6400))
+                                           for s in ((768, 768, q), (1536, 768, kv), (768, 768, q), (3072, 768, q), (768, 3072, q))], EPI_ACCUM, True),
     ]
+    if os.environ.get("CASES"):
+        cases = [c for c in cases if c[0].split()[0] in os.environ["CASES"].split(",")]
     rounds = int(os.environ.get("ROUNDS", "3"))
     for name, layout, shapes, epi, f32 in cases:
         best = {i: 0.0 for i in impls}
