@@ -169,10 +169,13 @@ int mmf_attn_bwd_grouped(const mmf_attn_problem* problems, int num_problems, int
 int mmf_attn_fwd_grouped_ex(const mmf_attn_problem* problems, int num_problems, int head_dim, float scale,
                             float dropout_p, const uint64_t* rng_state, uint32_t site, void* stream);
 /* Tuning hook: attention kernel generation (0 automatic [default] = 2; 1 register-staged, 128 query rows per
- * workgroup; 2 LDS-DMA ring, 256 query rows per workgroup, XCD-aware order, two waves per SIMD; 3 = forward only:
+ * workgroup; 2 LDS-DMA ring, 128 query rows per workgroup, XCD-aware order, three workgroups per CU; 3 = forward only:
  * one wave per SIMD, 512 registers, QK^T of tile j+1 software-pipelined under the softmax of tile j — faster per
- * workgroup, slower per CU than 2 at the MulT shapes, kept for A/B).  Same results up to f32 summation order and
- * the deferred running maximum; exists so that A/B timings can be interleaved inside one process. */
+ * workgroup, slower per CU than 2 at the MulT shapes; 4 = forward only: 8-wave workgroups whose two waves per SIMD
+ * alternate matrix and softmax phases between barriers (attention4.hip; equal to 2 at Tk = 2048, slower at the MulT
+ * lengths, kept selectable for tuning; MMF_ATTN_FWD_GEN=4 makes it the automatic choice).  1 and 3 exist only in
+ * `make LEGACY=1` builds.  Same results up to f32 summation order and the deferred running maximum; exists so that
+ * A/B timings can be interleaved inside one process. */
 int mmf_attn_select_impl(int impl);
 int mmf_attn_bwd_grouped_ex(const mmf_attn_problem* problems, int num_problems, int head_dim, float scale,
                             float dropout_p, const uint64_t* rng_state, uint32_t site, void* stream);

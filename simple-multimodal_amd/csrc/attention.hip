@@ -486,13 +486,18 @@ int mmf_attn_fwd2_launch(const mmf_attn_problem* problems, int n, int head_dim, 
                          const uint64_t* rng_state, uint32_t site, hipStream_t s);
 int mmf_attn_bwd2_launch(const mmf_attn_problem* problems, int n, int head_dim, float scale, float drop_p,
                          const uint64_t* rng_state, uint32_t site, hipStream_t s);
+// fourth-generation forward (attention4.hip: 8-wave ping-pong for the wide problems, second generation for the rest)
+int mmf_attn_fwd4_launch(const mmf_attn_problem* problems, int n, int head_dim, float scale, float drop_p,
+                         const uint64_t* rng_state, uint32_t site, hipStream_t s);
 #ifdef MMF_LEGACY_KERNELS
 int mmf_attn_fwd3_launch(const mmf_attn_problem* problems, int n, int head_dim, float scale, float drop_p,
                          const uint64_t* rng_state, uint32_t site, hipStream_t s);
 #endif
-static int g_attn_impl = 0;       // 0 automatic, 1 first generation, 2 second generation, 3 third-generation forward
+// 0 automatic, 1 first generation, 2 second generation, 3 third-generation forward, 4 fourth-generation forward
+static int g_attn_impl = 0;
+static const int g_attn_fwd_gen = [] { const char* e = getenv("MMF_ATTN_FWD_GEN"); return e ? atoi(e) : 2; }();   // automatic choice of the forward
 extern "C" int mmf_attn_select_impl(int impl) {
-  if (impl < 0 || impl > 3) MMF_FAIL(MMF_E_UNSUPPORTED, "mmf_attn_select_impl: impl=%d (0 auto, 1, 2, 3)", impl);
+  if (impl < 0 || impl > 4) MMF_FAIL(MMF_E_UNSUPPORTED, "mmf_attn_select_impl: impl=%d (0 auto, 1, 2, 3, 4)", impl);
 #ifndef MMF_LEGACY_KERNELS
   if (impl == 1 || impl == 3)
     MMF_FAIL(MMF_E_UNSUPPORTED, "mmf_attn_select_impl: generation %d (superseded) is only in builds made with `make LEGACY=1`", impl);
@@ -507,6 +512,9 @@ extern "C" int mmf_attn_fwd_grouped_ex(const mmf_attn_problem* problems, int num
   if (int rc = validate("mmf_attn_fwd_grouped", problems, num_problems, head_dim, false)) return rc;
   if (!(dropout_p >= 0.f) || dropout_p >= 1.f || (dropout_p > 0.f && !rng_state))
     MMF_FAIL(MMF_E_SHAPE, "mmf_attn_fwd_grouped_ex: dropout needs 0 <= p < 1 and an rng_state");
+  if (g_attn_impl == 4 || (g_attn_impl == 0 && g_attn_fwd_gen == 4))
+    return mmf_attn_fwd4_launch(problems, num_problems, head_dim, scale, dropout_p, rng_state, site,
+                                static_cast<hipStream_t>(stream));
 #ifndef MMF_LEGACY_KERNELS
   return mmf_attn_fwd2_launch(problems, num_problems, head_dim, scale, dropout_p, rng_state, site,
                               static_cast<hipStream_t>(stream));

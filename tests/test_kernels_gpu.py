@@ -630,8 +630,8 @@ def test_stack3_embed_and_rowmask():
     assert torch.equal(ym, xm.detach() * m[:, None]) and torch.equal(xm.grad, m[:, None].expand(B, d))
 
 
-@pytest.mark.parametrize("impl", [1, 2, 3])
-@pytest.mark.parametrize("Tq,Tk", [(512, 400), (400, 512), (30, 512), (512, 30), (300, 97), (257, 65)])
+@pytest.mark.parametrize("impl", [1, 2, 3, 4])
+@pytest.mark.parametrize("Tq,Tk", [(512, 400), (400, 512), (30, 512), (512, 30), (300, 97), (257, 65), (129, 200), (600, 1000)])
 def test_attention_generations_at_mult_shapes(impl, Tq, Tk):
     """Every attention generation (mmf_attn_select_impl) on the MulT sequence shapes: several 256-row query chunks
     with balanced sizes (400 -> 224 + 176), ragged last tiles whose second 32-key block is pure padding (400 = 6
