@@ -193,7 +193,7 @@ void ln_bwd_kernel(const LnArgs a) {
 // second phase: dgamma[j] += sum over the problem's workgroups of their partials.  thread = column,
 // blockIdx.z = one of FIN_SLICES slices of the workgroup range; each slice ends in one f32 atomic per
 // column (FIN_SLICES adders per address).
-constexpr int FIN_SLICES = 32;
+constexpr int FIN_SLICES = 64;
 __global__ __launch_bounds__(256)
 void ln_bwd_finalize_kernel(const LnArgs a) {
   const int pi = blockIdx.y;
@@ -203,14 +203,25 @@ void ln_bwd_finalize_kernel(const LnArgs a) {
   const int per = (nb + FIN_SLICES - 1) / FIN_SLICES;
   const int lo = b0 + blockIdx.z * per, hi = min(b0 + nb, lo + per);
   if (lo >= hi) return;
-  float sg = 0.f, sb = 0.f;
-  for (int b = lo; b < hi; ++b) {
-    const float* w = a.ws + (size_t)b * 2 * a.d;
-    sg += w[col];
-    sb += w[a.d + col];
+  // four independent row loads in flight per thread: written as one running sum the loop is a chain of exposed HBM round
+  // trips (16 us per launch for 12 MB of partials, measured in round 2)
+  float sg[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f};
+  int b = lo;
+  for (; b + 4 <= hi; b += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float* w = a.ws + (size_t)(b + u) * 2 * a.d;
+      sg[u] += w[col];
+      sb[u] += w[a.d + col];
+    }
   }
-  atomicAdd(a.p[pi].dgamma + col, sg);
-  atomicAdd(a.p[pi].dbeta + col, sb);
+  for (; b < hi; ++b) {
+    const float* w = a.ws + (size_t)b * 2 * a.d;
+    sg[0] += w[col];
+    sb[0] += w[a.d + col];
+  }
+  atomicAdd(a.p[pi].dgamma + col, (sg[0] + sg[1]) + (sg[2] + sg[3]));
+  atomicAdd(a.p[pi].dbeta + col, (sb[0] + sb[1]) + (sb[2] + sb[3]));
 }
 
 int check_common(const char* who, const mmf_ln_problem* p, int n, int d) {
