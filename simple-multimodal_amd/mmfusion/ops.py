@@ -259,6 +259,15 @@ _pending_wgrad: List[tuple] = []
 _WGRAD_SIDE = _os.environ.get("MMF_WGRAD_SIDE", "0") == "1"
 _WGRAD_CHUNK = int(_os.environ.get("MMF_WGRAD_CHUNK", "800"))
 _wgrad_stream: Optional[torch.cuda.Stream] = None
+# Early flush (MMF_WGRAD_EARLY, default on): the number of weight-gradient problems a backward queues is the same every
+# step, so when the count of the previous backward is reached the whole deferred launch is issued at once on its own
+# stream instead of from the end-of-backward callback.  What the backward still has to do after its last Linear (the
+# N-way input-gradient sums of the fan-outs: three HBM-bound kernels, 40 us + launch gaps at the MulT bench shapes)
+# then runs beside the wgrad launch instead of in front of it.  A backward that queues more, or fewer, than the last one
+# is still complete: whatever is pending when the callback runs is issued there, and the callback joins the stream.
+_WGRAD_EARLY = _os.environ.get("MMF_WGRAD_EARLY", "1") == "1"
+_expected_wgrad = 0
+_early_issued = 0
 _callback_queued = False
 _pending_tiles = 0
 
@@ -326,12 +335,16 @@ def _issue_wgrad(pend: List[tuple]) -> None:
             gemm_group(GEMM_TN, group, (0 if overwrite else EPI_ACCUM) | (EPI_COLSUM_A if has_bias else 0))
 
 
-def _issue_wgrad_side(pend: List[tuple]) -> None:
+def _issue_wgrad_side(pend: List[tuple], all_streams: bool = False) -> None:
     global _wgrad_stream
     if _wgrad_stream is None:
         _wgrad_stream = torch.cuda.Stream()
     cur = torch.cuda.current_stream()
     _wgrad_stream.wait_stream(cur)                       # the queued dy / x are complete on the main stream
+    if all_streams:                                      # ... and on the branch streams other backward nodes ran on
+        for st in _branch_streams:
+            if st != cur:
+                _wgrad_stream.wait_stream(st)
     with torch.cuda.stream(_wgrad_stream):
         _issue_wgrad(pend)
     for q in pend:                                       # keep the operands' memory until the side kernels ran
@@ -397,9 +410,11 @@ def issue_wgrad(pend: List[tuple]) -> None:
 
 
 def _flush_wgrad() -> None:
-    global _pending_wgrad, _callback_queued, _pending_tiles
+    global _pending_wgrad, _callback_queued, _pending_tiles, _expected_wgrad, _early_issued
     pend, _pending_wgrad = _pending_wgrad, []
     _callback_queued, _pending_tiles = False, 0
+    early, _early_issued = _early_issued, 0
+    _expected_wgrad = early + len(pend)                  # what the next backward is expected to queue
     if _branch_streams:                                  # operands queued by backward nodes that ran on a branch stream
         cur = torch.cuda.current_stream()
         join_branch_streams()
@@ -415,6 +430,10 @@ def _flush_wgrad() -> None:
         if _wgrad_stream is not None:
             torch.cuda.current_stream().wait_stream(_wgrad_stream)      # gradients complete when backward returns
         return
+    if early and _wgrad_stream is not None:
+        # gradients complete when backward returns — and BEFORE any left-over problem is issued here: a left-over may
+        # accumulate into a region the early launch is still writing (a weight used twice)
+        torch.cuda.current_stream().wait_stream(_wgrad_stream)
     if pend:
         _issue_wgrad(pend)
 
@@ -437,6 +456,12 @@ def queue_wgrad(dy: torch.Tensor, x: torch.Tensor, wgrad: torch.Tensor, bgrad: O
         torch.autograd.Variable._execution_engine.queue_callback(_flush_wgrad)
         _callback_queued = True
     _pending_wgrad.append((dy, x, wgrad, bgrad, None, overwrite))
+    global _early_issued
+    if (_WGRAD_EARLY and not _WGRAD_SIDE and not _MANUAL_FLUSH and _expected_wgrad and not _early_issued
+            and len(_pending_wgrad) == _expected_wgrad):
+        pend, _pending_wgrad = _pending_wgrad, []
+        _early_issued = len(pend)
+        _issue_wgrad_side(pend, all_streams=True)
     if _WGRAD_SIDE:
         _pending_tiles += ((wgrad.shape[0] + 255) // 256) * ((wgrad.shape[1] + 127) // 128)
         if _pending_tiles >= _WGRAD_CHUNK:

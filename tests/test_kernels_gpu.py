@@ -709,11 +709,15 @@ def test_fused_adamw_device_schedule_many_steps_without_host_sync():
             assert abs(float(opt.hparams[0]) - one_cycle_lr(steps - 1, total, max_lr)) < 1e-9 + 1e-6 * max_lr
 
 
+@pytest.mark.parametrize("short_before", [False, True])
 @pytest.mark.parametrize("lazy", [False, True])
-def test_linear_applied_twice_accumulates_both_uses(lazy):
+def test_linear_applied_twice_accumulates_both_uses(lazy, short_before):
     """a weight used twice in one forward queues two deferred wgrad problems for ONE gradient
     region; they must not share a grouped launch (non-atomic accumulate) nor run accumulate-before-overwrite under
-    lazy zeroing.  Three uses (the lazy race needs three), with and without a bias, against torch autograd."""
+    lazy zeroing.  Three uses (the lazy race needs three), with and without a bias, against torch autograd.
+    short_before: a backward that queues only TWO problems runs first, so the early flush (ops.py, MMF_WGRAD_EARLY)
+    fires after the second of the five problems on its own stream and the other three — accumulates into the same two
+    regions — are issued from the end-of-backward callback: they must wait for the early launch."""
     from mmfusion import arena as arena_mod
     from mmfusion.ops import W
     torch.manual_seed(0)
@@ -732,6 +736,9 @@ def test_linear_applied_twice_accumulates_both_uses(lazy):
         return x.grad
     ar.zero_grad()
     run_hip()                                   # teaches the arena its wgrad-managed regions
+    if short_before:
+        xs = x0.clone().requires_grad_(True)
+        (ops.linear(ops.linear(xs, W(mod["a"].weight), W(mod["a"].bias)), W(mod["b"].weight)).float() * 1e-2).sum().backward()
     if lazy:
         ar.grads.fill_(7.0)                     # stale values a lazy zero must not let through
     ar.zero_grad(lazy=lazy)
