@@ -553,10 +553,11 @@ def main():
     # kernel would be charged the other's time.  The dominant kernel (the deferred wgrad launch) runs after the
     # join either way, so its duration is the same in both modes (and in the rocprofv3 summary).
     from models import fusion_layers as _fl
-    saved_streams = (_fl._MULT_STREAMS, _fl._BRANCH_STREAM)
-    _fl._MULT_STREAMS, _fl._BRANCH_STREAM = 1, False
+    from mmfusion import ops as _ops
+    saved_streams = (_fl._MULT_STREAMS, _fl._BRANCH_STREAM, _ops._WGRAD_EARLY)
+    _fl._MULT_STREAMS, _fl._BRANCH_STREAM, _ops._WGRAD_EARLY = 1, False, False
     prof = kernel_profile(profile_step, args.profile_steps)
-    _fl._MULT_STREAMS, _fl._BRANCH_STREAM = saved_streams
+    _fl._MULT_STREAMS, _fl._BRANCH_STREAM, _ops._WGRAD_EARLY = saved_streams
     dom = max(prof, key=lambda k: prof[k]["ms_total"])
     dsec = prof[dom]["ms_total"] * 1e-3
     ach = prof[dom]["flops_total"] / dsec / 1e12

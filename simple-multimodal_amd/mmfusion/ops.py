@@ -259,13 +259,15 @@ _pending_wgrad: List[tuple] = []
 _WGRAD_SIDE = _os.environ.get("MMF_WGRAD_SIDE", "0") == "1"
 _WGRAD_CHUNK = int(_os.environ.get("MMF_WGRAD_CHUNK", "800"))
 _wgrad_stream: Optional[torch.cuda.Stream] = None
-# Early flush (MMF_WGRAD_EARLY, default on): the number of weight-gradient problems a backward queues is the same every
+# Early flush (MMF_WGRAD_EARLY=1; measured +0.4 % and left OFF by default — with it the dominant kernel shares the chip with
+# the input-gradient sums, so its duration in a profile of the timed steps no longer equals its stand-alone duration, which
+# is what bench.py's roofline is built on): the number of weight-gradient problems a backward queues is the same every
 # step, so when the count of the previous backward is reached the whole deferred launch is issued at once on its own
 # stream instead of from the end-of-backward callback.  What the backward still has to do after its last Linear (the
 # N-way input-gradient sums of the fan-outs: three HBM-bound kernels, 40 us + launch gaps at the MulT bench shapes)
 # then runs beside the wgrad launch instead of in front of it.  A backward that queues more, or fewer, than the last one
 # is still complete: whatever is pending when the callback runs is issued there, and the callback joins the stream.
-_WGRAD_EARLY = _os.environ.get("MMF_WGRAD_EARLY", "1") == "1"
+_WGRAD_EARLY = _os.environ.get("MMF_WGRAD_EARLY", "0") == "1"
 _expected_wgrad = 0
 _early_issued = 0
 _callback_queued = False

@@ -736,13 +736,19 @@ def test_linear_applied_twice_accumulates_both_uses(lazy, short_before):
         return x.grad
     ar.zero_grad()
     run_hip()                                   # teaches the arena its wgrad-managed regions
+    from mmfusion import ops as ops_mod
+    saved_early = ops_mod._WGRAD_EARLY
+    ops_mod._WGRAD_EARLY = short_before or saved_early      # the early flush is off by default: exercise it here
     if short_before:
         xs = x0.clone().requires_grad_(True)
         (ops.linear(ops.linear(xs, W(mod["a"].weight), W(mod["a"].bias)), W(mod["b"].weight)).float() * 1e-2).sum().backward()
     if lazy:
         ar.grads.fill_(7.0)                     # stale values a lazy zero must not let through
     ar.zero_grad(lazy=lazy)
-    gx = run_hip()
+    try:
+        gx = run_hip()
+    finally:
+        ops_mod._WGRAD_EARLY = saved_early
     ar.finalize_grads()
     torch.cuda.synchronize()
     wa, ba, wb = (t.detach().to(torch.bfloat16).float().requires_grad_(True) for t in
