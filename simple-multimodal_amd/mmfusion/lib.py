@@ -13,7 +13,7 @@ import os
 from typing import List, Optional, Sequence
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmmfusion.so")
+LIB_PATH = os.environ.get("MMF_LIB_PATH") or os.path.join(_HERE, "libmmfusion.so")     # MMF_LIB_PATH: A/B of two builds in one gpurun call
 
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 EPI_BIAS, EPI_RELU, EPI_MASK_AUX, EPI_ADD_AUX, EPI_ACCUM, EPI_COLSUM_A, EPI_DROPOUT = 1, 2, 4, 8, 16, 32, 64
