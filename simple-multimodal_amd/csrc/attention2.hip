@@ -234,8 +234,8 @@ void attn_fwd2n_kernel(const AttnArgs2 a) {
   const int nb = (min(P.Tq, q0 + rpc) - q0 + 31) >> 5;      // 32-row query blocks in this chunk (1..4)
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int qs = q0 + 32 * wave, pidx = a.orig[pi];
-  if (wave < nb) fwd2_wave<DH, DROP, 1, 2>(a, P, pidx, bh, qs, smem);
-  else           fwd2_wave<DH, DROP, 0, 2>(a, P, pidx, bh, qs, smem);
+  if (wave < nb && !(a.debug & 2)) fwd2_wave<DH, DROP, 1, 2>(a, P, pidx, bh, qs, smem);
+  else                             fwd2_wave<DH, DROP, 0, 2>(a, P, pidx, bh, qs, smem);
 }
 
 // ================================================================================================
