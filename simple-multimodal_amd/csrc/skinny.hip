@@ -13,6 +13,7 @@
 //                                                                 (ds_read_b64_tr_b16).
 // wgrad (dW = dy^T x, output-bound) stays on the grouped TN kernel via the deferred launch.
 #include "mmf_internal.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -110,18 +111,22 @@ void skinny_fwd_kernel(const SkinnyArgs a) {
 // ---- dgrad -----------------------------------------------------------------------------------------------
 // X := dy [M][N_out] (bf16), W [N_out][K_in], Y := dx [M][K_in]; aux (bf16 [M][K_in], optional) is the saved
 // activation whose sign gates the gradient (ReLU / dropout mask), alpha the 1/(1-p) of a dropout backward.
-template <bool OUT_F32>
+// CT = 16-column tiles of k_in per workgroup (strip width 16 CT).  4 is the streaming form; a launch whose 64-column strips would
+// leave most CUs idle (K_in = 768: twelve workgroups, 21 us of latency chain for 1.2 MB of weights — 8 % of the hier-seq
+// training step's kernel time in round 2) takes 2 or 1: four times the workgroups, each reading 32-byte row pieces that its
+// neighbours' strips complete in L2.
+template <bool OUT_F32, int CT>
 __global__ __launch_bounds__(SK_THREADS)
 void skinny_dgrad_kernel(const SkinnyArgs a) {
-  constexpr int SB = (64 + 8) * 2;                                       // padded slice row: 64 k_in + 8
-  constexpr int RED_BYTES = (int)sizeof(float) * (SK_WAVES - 1) * 4 * MAX_MT * 64 * 4;     // 112 KiB
+  constexpr int SB = (16 * CT + 8) * 2;                                  // padded slice row: 16 CT k_in + 8
+  constexpr int RED_BYTES = (int)sizeof(float) * (SK_WAVES - 1) * CT * MAX_MT * 64 * 4;    // 112 KiB at CT = 4
   constexpr int SLICE_BYTES = SK_WAVES * 32 * SB;
   __shared__ __attribute__((aligned(16))) char smem[SLICE_BYTES > RED_BYTES ? SLICE_BYTES : RED_BYTES];
   int pi = 0;
   while (pi + 1 < a.nprob && (int)blockIdx.x >= a.blk_start[pi + 1]) ++pi;
   const mmf_skinny_problem& P = a.p[pi];
   const int M = P.M, Nout = P.N, Kin = P.K;
-  const int c0 = ((int)blockIdx.x - a.blk_start[pi]) * 64;              // first k_in column of this strip
+  const int c0 = ((int)blockIdx.x - a.blk_start[pi]) * (16 * CT);       // first k_in column of this strip
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int mt = (M + 15) >> 4;
   const unsigned short* __restrict__ dY = static_cast<const unsigned short*>(P.X);
@@ -130,19 +135,19 @@ void skinny_dgrad_kernel(const SkinnyArgs a) {
 
   const int steps = (Nout + 31) >> 5, per = (steps + SK_WAVES - 1) / SK_WAVES;
   const int s0 = wave * per, s1 = min(steps, s0 + per);
-  f32x4_t acc[4][MAX_MT];                                                // [k_in tile][m tile]
+  f32x4_t acc[CT][MAX_MT];                                               // [k_in tile][m tile]
 #pragma unroll
-  for (int c = 0; c < 4; ++c)
+  for (int c = 0; c < CT; ++c)
 #pragma unroll
     for (int t = 0; t < MAX_MT; ++t) acc[c][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
-  u32x4_t stage[4];
+  u32x4_t stage[CT];
   bf16x8_t yf[MAX_MT], yn_[MAX_MT];
-  auto fetch = [&](int s, bf16x8_t (&y)[MAX_MT]) {                       // 32 x 64 block of W (16-B chunks, coalesced) + dy
+  auto fetch = [&](int s, bf16x8_t (&y)[MAX_MT]) {                       // 32 x 16 CT block of W (16-B chunks, coalesced) + dy
     const int r0 = s << 5;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int ch = lane + 64 * i, row = ch >> 3, col = (ch & 7) << 3;
+    for (int i = 0; i < CT; ++i) {
+      const int ch = lane + 64 * i, row = ch / (2 * CT), col = (ch % (2 * CT)) << 3;
       u32x4_t v = {0u, 0u, 0u, 0u};
       if (r0 + row < Nout && c0 + col < Kin) v = *reinterpret_cast<const u32x4_t*>(W + (size_t)(r0 + row) * P.ldw + c0 + col);
       stage[i] = v;
@@ -154,13 +159,13 @@ void skinny_dgrad_kernel(const SkinnyArgs a) {
   if (s0 < s1) fetch(s0, yf);
   for (int s = s0; s < s1; ++s) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int ch = lane + 64 * i, row = ch >> 3, col = (ch & 7) << 3;
+    for (int i = 0; i < CT; ++i) {
+      const int ch = lane + 64 * i, row = ch / (2 * CT), col = (ch % (2 * CT)) << 3;
       *reinterpret_cast<u32x4_t*>(slice + row * SB + col * 2) = stage[i];
     }
     if (s + 1 < s1) fetch(s + 1, yn_);                                   // next block in flight under the MFMAs
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < CT; ++c) {
       // W^T fragment: lane (i = k_in column c*16 + (l & 15), k = n_out 8g + e) from rows 8g .. 8g+7 of the slice
       const char* ap = slice + (8 * g + q) * SB + (c * 16 + 4 * pp) * 2;
       const s16x4_t lo = lds_read_tr16(ap);
@@ -175,19 +180,19 @@ void skinny_dgrad_kernel(const SkinnyArgs a) {
     for (int t = 0; t < MAX_MT; ++t) yf[t] = yn_[t];
   }
   __syncthreads();                                                       // slices are dead: reuse LDS for the sums
-  float* red = reinterpret_cast<float*>(smem);                           // [7 waves][4 c][MAX_MT][64 lanes][4]
+  float* red = reinterpret_cast<float*>(smem);                           // [7 waves][CT c][MAX_MT][64 lanes][4]
   if (wave > 0) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
+    for (int c = 0; c < CT; ++c)
 #pragma unroll
       for (int t = 0; t < MAX_MT; ++t)
-        if (t < mt) *reinterpret_cast<f32x4_t*>(red + ((((wave - 1) * 4 + c) * MAX_MT + t) * 64 + lane) * 4) = acc[c][t];
+        if (t < mt) *reinterpret_cast<f32x4_t*>(red + ((((wave - 1) * CT + c) * MAX_MT + t) * 64 + lane) * 4) = acc[c][t];
   }
   __syncthreads();
   if (wave == 0) {
     const unsigned short* __restrict__ aux = static_cast<const unsigned short*>(P.aux);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < CT; ++c) {
       const int k = c0 + c * 16 + (g << 2);                              // D[i = k_in][j = m]
 #pragma unroll
       for (int t = 0; t < MAX_MT; ++t) {
@@ -195,7 +200,7 @@ void skinny_dgrad_kernel(const SkinnyArgs a) {
         if (t < mt && m < M && k < Kin) {
           f32x4_t v = acc[c][t];
 #pragma unroll
-          for (int w = 0; w < SK_WAVES - 1; ++w) v += *reinterpret_cast<const f32x4_t*>(red + (((w * 4 + c) * MAX_MT + t) * 64 + lane) * 4);
+          for (int w = 0; w < SK_WAVES - 1; ++w) v += *reinterpret_cast<const f32x4_t*>(red + (((w * CT + c) * MAX_MT + t) * 64 + lane) * 4);
           if (a.flags & MMF_EPI_MASK_AUX) {
             const u32x2_t x = *reinterpret_cast<const u32x2_t*>(aux + (size_t)m * P.ldaux + k);
             v[0] = bf16lo(x[0]) > 0.f ? v[0] : 0.f; v[1] = bf16hi(x[0]) > 0.f ? v[1] : 0.f;
@@ -251,12 +256,24 @@ extern "C" int mmf_skinny_linear_dgrad(const mmf_skinny_problem* problems, int n
                                        int out_f32, void* stream) {
   if (int rc = check("mmf_skinny_linear_dgrad", problems, num_problems, flags, true)) return rc;
   SkinnyArgs a; a.nprob = num_problems; a.flags = flags; a.alpha = alpha;
+  int wide = 0;
+  for (int i = 0; i < num_problems; ++i) wide += (problems[i].K + 63) / 64;
+  // strip width: 64 columns when that already gives the chip a workgroup per two CUs, else 32, else 16 (MMF_SKINNY_CT pins it)
+  static const int pin = [] { const char* e = getenv("MMF_SKINNY_CT"); const int v = e ? atoi(e) : 0; return (v == 1 || v == 2 || v == 4) ? v : 0; }();
+  const int ct = pin ? pin : wide >= 128 ? 4 : wide >= 48 ? 2 : 1;
   int total = 0;
-  for (int i = 0; i < num_problems; ++i) { a.blk_start[i] = total; total += (problems[i].K + 63) / 64; a.p[i] = problems[i]; }
+  for (int i = 0; i < num_problems; ++i) { a.blk_start[i] = total; total += (problems[i].K + 16 * ct - 1) / (16 * ct); a.p[i] = problems[i]; }
   a.blk_start[num_problems] = total;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (out_f32) hipLaunchKernelGGL(skinny_dgrad_kernel<true>, dim3(total), dim3(SK_THREADS), 0, s, a);
-  else         hipLaunchKernelGGL(skinny_dgrad_kernel<false>, dim3(total), dim3(SK_THREADS), 0, s, a);
+  if (out_f32) {
+    if (ct == 4)      hipLaunchKernelGGL((skinny_dgrad_kernel<true, 4>), dim3(total), dim3(SK_THREADS), 0, s, a);
+    else if (ct == 2) hipLaunchKernelGGL((skinny_dgrad_kernel<true, 2>), dim3(total), dim3(SK_THREADS), 0, s, a);
+    else              hipLaunchKernelGGL((skinny_dgrad_kernel<true, 1>), dim3(total), dim3(SK_THREADS), 0, s, a);
+  } else {
+    if (ct == 4)      hipLaunchKernelGGL((skinny_dgrad_kernel<false, 4>), dim3(total), dim3(SK_THREADS), 0, s, a);
+    else if (ct == 2) hipLaunchKernelGGL((skinny_dgrad_kernel<false, 2>), dim3(total), dim3(SK_THREADS), 0, s, a);
+    else              hipLaunchKernelGGL((skinny_dgrad_kernel<false, 1>), dim3(total), dim3(SK_THREADS), 0, s, a);
+  }
   MMF_CHECK_LAUNCH("mmf_skinny_linear_dgrad");
   return MMF_OK;
 }
