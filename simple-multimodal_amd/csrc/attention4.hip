@@ -103,7 +103,32 @@ __device__ __forceinline__ void fwd4_wave(const AttnArgs2& a, const mmf_attn_pro
   const unsigned short* Vg = static_cast<const unsigned short*>(P.V) + (size_t)b * Tk * P.ldv + h * DH;
   const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(Kg), 0, Tk * P.ldk * 2, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(Vg), 0, Tk * P.ldv * 2, 0x00020000);
-  auto issue = [&](int j) { dma_pair8<DH>(rsK, rsV, P.ldk, P.ldv, smem + (j & (NST4 - 1)) * STAGE_B, j, wave, lane); };
+  // Per-lane offsets of this wave's (at most four) pieces inside a tile, computed once; a tile is then fetched through a
+  // descriptor whose base is the tile's first row and whose range ends after row Tk - 1 (rows past Tk read as zeros), so
+  // the loop issues its DMA with scalar arithmetic only.
+  constexpr int CPR = DH / 8 + 1, PIECES = TILE_B / 1024, NI = (2 * PIECES + 7) / 8;
+  unsigned voff[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int p = wave + 8 * i, isy = p >= PIECES, c = (p - isy * PIECES) * 64 + lane;
+    const int row = c / CPR, ch = c % CPR;
+    voff[i] = ch == CPR - 1 ? OOB : (unsigned)(row * (isy ? P.ldv : P.ldk) * 2 + ch * 16);
+  }
+  (void)rsK; (void)rsV;
+  auto issue = [&](int j) {
+    char* st = smem + (j & (NST4 - 1)) * STAGE_B;
+    const int rows_left = max(0, Tk - 64 * j);
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(Kg + (size_t)64 * j * P.ldk), 0, rows_left * P.ldk * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(Vg + (size_t)64 * j * P.ldv), 0, rows_left * P.ldv * 2, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int p = wave + 8 * i;
+      if (p < 2 * PIECES) {
+        if (p < PIECES) __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lds_void_t*)(st + p * 1024), 16, voff[i], 0, 0, 0);
+        else            __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_void_t*)(st + p * 1024), 16, voff[i], 0, 0, 0);
+      }
+    }
+  };
   const int n = (Tk + 63) / 64;
 
   // the first tiles of the ring, then the Q fragments straight from HBM; the empty asm makes the compiler place its wait
@@ -113,7 +138,7 @@ __device__ __forceinline__ void fwd4_wave(const AttnArgs2& a, const mmf_attn_pro
   unsigned long long seg[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tlast = __builtin_readcyclecounter();
 #endif
-  const int npro = min(n, NST4);
+  const int npro = min(n, 2);                             // tiles 2, 3, ... follow when slots 0, 2, ... open
   for (int j = 0; j < npro; ++j) if (!(a.debug & 32)) issue(j);
   bf16x8_t qf[KS];
 #pragma unroll
@@ -139,9 +164,24 @@ __device__ __forceinline__ void fwd4_wave(const AttnArgs2& a, const mmf_attn_pro
 
   // matrix phase j: P.V of tile j - 1 (if any), then the raw scores of tile j (if any)
   auto mphase = [&](int j) {
+    // the K fragments of tile j (both blocks) are requested first, so that they land under the P.V chain of tile j - 1
+    bf16x8_t kf[2][KS];
+    const bool qk0 = j < n, qk1 = j < n && j * 64 + 32 < Tk;
+    if (qk0) {
+      const char* sK = smem + (j & (NST4 - 1)) * STAGE_B;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) kf[0][ks] = row_frag<DH>(sK, 0, ks, lane);
+      if (qk1) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) kf[1][ks] = row_frag<DH>(sK, 32, ks, lane);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
     if (j > 0) {
       const unsigned va = smem_lds + ((j - 1) & (NST4 - 1)) * STAGE_B + TILE_B + troff;
       const int kb = (j - 1) * 64;
+      // (six fragments of read-ahead over both blocks were tried: P.V 820-1,050 -> 950-1,220 cycles — more LDS reads in flight
+      //  are slower here, as in the wgrad kernel)
       auto pv = [&](auto KTc) {
         constexpr int KT = decltype(KTc)::value;
         if (kb + 32 * KT >= Tk) return;
@@ -154,22 +194,17 @@ __device__ __forceinline__ void fwd4_wave(const AttnArgs2& a, const mmf_attn_pro
       pv(std::integral_constant<int, 1>{});
       ASTAMP(11);
     }
-    if (j < n) {
-      const char* sK = smem + (j & (NST4 - 1)) * STAGE_B;
-      const int kb = j * 64;
-      auto qk = [&](auto KTc) {
-        constexpr int KT = decltype(KTc)::value;
-        if (kb + 32 * KT >= Tk) return;
-        bf16x8_t kf[KS];
+    if (qk0) {
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) kf[ks] = row_frag<DH>(sK, 32 * KT, ks, lane);
+      for (int r = 0; r < 16; ++r) s[0][r] = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[KT][r] = 0.f;
+      for (int ks = 0; ks < KS; ++ks) s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0][ks], qf[ks], s[0], 0, 0, 0);
+      if (qk1) {
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) s[KT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], s[KT], 0, 0, 0);
-      };
-      qk(std::integral_constant<int, 0>{});
-      qk(std::integral_constant<int, 1>{});
+        for (int r = 0; r < 16; ++r) s[1][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1][ks], qf[ks], s[1], 0, 0, 0);
+      }
     }
   };
   // softmax phase j: one running-maximum decision for the whole tile, then the probabilities of its (one or two) blocks
@@ -242,7 +277,7 @@ __device__ __forceinline__ void fwd4_wave(const AttnArgs2& a, const mmf_attn_pro
 
   // slot bookkeeping (identical for every wave of the workgroup: the barrier count must not depend on group or activity)
   auto slot_open = [&](int sl) {
-    if (!(sl & 1) && sl >= 4) {                              // slot 2 t - 4 opens: the stage of tile t - 4 is free
+    if (!(sl & 1)) {                                         // slot 2 t - 4 opens: the stage of tile t - 4 is free (t >= 2)
       const int t = (sl + 4) >> 1;
       if (t < n && !(a.debug & 1)) issue(t);
       ASTAMP(5);
@@ -253,7 +288,7 @@ __device__ __forceinline__ void fwd4_wave(const AttnArgs2& a, const mmf_attn_pro
     if (sl & 1) {                                            // tile t is needed from the next slot on
       const int t = (sl + 1) >> 1;
       if (t < n) {
-        const int newest = min(max(NST4 - 1, t + 1), n - 1);  // youngest tile issued so far
+        const int newest = min(t + 1, n - 1);                // youngest tile issued so far
         wait_vm((newest - t) * npw);
       }
       ASTAMP(3);
