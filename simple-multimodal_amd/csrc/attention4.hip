@@ -379,8 +379,9 @@ int mmf_attn_fwd4_launch(const mmf_attn_problem* problems, int n, int head_dim, 
   if (int rc = check_ranges("mmf_attn_fwd_grouped", problems, n)) return rc;
   mmf_attn_problem wide[MMF_ATTN_MAX_PROBLEMS], narrow[MMF_ATTN_MAX_PROBLEMS];
   int wide_idx[MMF_ATTN_MAX_PROBLEMS], narrow_idx[MMF_ATTN_MAX_PROBLEMS], nw = 0, nn = 0;
+  static const int all4 = [] { const char* e = getenv("MMF_ATTN4_ALL"); return e ? atoi(e) : 0; }();   // A/B: narrow problems too
   for (int i = 0; i < n; ++i) {
-    if (problems[i].Tq > 128 && problems[i].Tk > 64) { wide[nw] = problems[i]; wide_idx[nw++] = i; }
+    if (all4 || (problems[i].Tq > 128 && problems[i].Tk > 64)) { wide[nw] = problems[i]; wide_idx[nw++] = i; }
     else                                             { narrow[nn] = problems[i]; narrow_idx[nn++] = i; }
   }
   if (nw) {
