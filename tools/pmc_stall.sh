@@ -1,8 +1,8 @@
 # Wave-stall / LDS / L2 counters per kernel of the eager MulT step (one counter set per pass).
-#   gpurun -- 'bash tools/pmc_stall.sh && python3 tools/pmc_stall_summary.py gpurun_out/r01s profiles/r01b_pmc_stalls.txt'
+#   gpurun -- 'bash tools/pmc_stall.sh && python3 tools/pmc_stall_summary.py gpurun_out/r01s profiles/<round>_pmc_stalls.txt'
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r01s
+O=gpurun_out/${TAG:-r01}s
 rm -rf $O && mkdir -p $O
 export MMF_MULT_STREAMS=1 MMF_HIER_STREAMS=0
 rocprofv3 -L > $O/avail.txt 2>&1
