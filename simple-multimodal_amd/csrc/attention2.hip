@@ -1,36 +1,50 @@
-// Grouped fused attention, second generation (forward): fat workgroups + LDS-DMA.
+// Grouped fused attention (forward, dQ, dK/dV): fat workgroups, LDS-DMA ring, one dual-use LDS image.
 //
-// What changed against attention.hip (kept for A/B behind mmf_attn_select_impl(1)) and why — the first
-// generation's launch fetched 3.1x the algorithmic bytes (profiles/r01_pmc_traffic.json: 324 MB per launch)
-// because the four 128-row query tiles of one (b, h) landed on four different XCDs and each re-read K/V
-// through its own L2, and it was bound by per-workgroup fixed cost (profiles/r01_attention_ablation.txt):
-//   * a workgroup (4 waves) covers up to 256 query rows of one (b, h); a wave owns TWO 32-row query blocks,
-//     so every K fragment (ds_read_b128) and V^T fragment (ds_read_b64_tr_b16) feeds two MFMAs and K/V are
-//     fetched once per 256 query rows instead of once per 128;
-//   * workgroup ids are remapped so that the chunks of one (b, h) (and neighbouring heads of one batch
-//     row) run on the SAME XCD (blockIdx % 8): the second chunk's K/V come from that XCD's L2;
-//   * K/V tiles go HBM/L2 -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds), 2-stage ring, the next tile's
-//     13 + 13 one-KiB pieces in flight under the current tile's MFMAs: no staging registers (the two query
-//     blocks' state is 208 of the 256 registers a 2-waves-per-SIMD kernel may use) and no ds_write pass;
-//     rows past Tk and the 16-B pad chunk of each row come back as zeros from the buffer range check;
-//   * softmax: scores stay raw in the accumulators, p = exp2(fma(s, c, -m)) is one FMA + one v_exp per
-//     score; the running maximum is only raised when some row's tile maximum exceeds it by more than
-//     2^DEFER (guide T13: P <= 2^DEFER instead of <= 1, exact after normalisation because m, l and O are
-//     rescaled together and the tile's P is exponentiated after the decision);
-//   * problems are launched heaviest first so the 30-row problems fill the tail.
-// Fragment layouts, the padded [64][DH+8] image and the P^T-as-operand orientation are those of
-// attention.hip (attn_helpers.h).
+// Structure (rounds 1-2; measurements behind each choice in DESIGN.md section 5):
+//   * all attention problems of a stage (the six cross blocks, or the three self-attentions, of a MulT pass — unequal
+//     Tq / Tk) go out as ONE launch; workgroup ids are remapped so that the chunks of one (b, h) (and neighbouring heads
+//     of one batch row) run on the SAME XCD (blockIdx % 8) and share its L2;
+//   * products are oriented so that every probability tile stays in registers between its two uses: forward / dQ compute
+//     S^T = K.Q^T (query on the lane: row max / sum / LSE / delta are per-lane scalars, P^T feeds O^T = V^T.P^T and dS^T
+//     feeds dQ^T = K^T.dS^T from the accumulator), dK/dV computes S = Q.K^T (key on the lane; a wave keeps dK^T, dV^T
+//     of its 32 keys in accumulators while the workgroup sweeps the queries; no atomics, deterministic);
+//   * swept tiles (K/V in forward and dQ; Q/dO/LSE/delta in dK/dV) go HBM/L2 -> LDS by LDS-DMA into a 2-stage ring, the
+//     next tile in flight under the current tile's MFMAs; rows past T come back as zeros from the buffer range check;
+//   * softmax on raw scores, p = exp2(fma(s, c, -m)); the running maximum is raised only when a row's block maximum
+//     exceeds it by 2^DEFER (guide T13), 32-key blocks, blocks that hold only padding are skipped;
+//   * transposed operands by asm ds_read_b64_tr_b16 with counted lgkmcnt waits.
+// Round 3 (each from a measurement, profiles/r03_attn_*):
+//   * ONE LDS image for row reads and transposed reads (attn_helpers.h: 8-row x 32-column subtiles, XOR swizzle) instead
+//     of 16-byte padded rows: the transposed reads were 2-way bank-conflicted, and the LDS port is as busy as the matrix
+//     pipe in these kernels (~1 KiB of fragment reads per MFMA);
+//   * prologue loads (Q; Q, dO, O; K, V) issued together behind one wait instead of 6 / 18 / 12 serial round trips;
+//   * per-lane LDS-DMA source offsets computed once per wave, tiles addressed through per-tile descriptors (SALU only).
 #include "attn2_common.h"
 
 namespace {
 
-// One wave of the forward: NQ (0, 1 or 2) query blocks of 32 rows at rows qs and qs + 128.  Waves with
-// NQ == 0 only take part in the K/V staging and the barriers.
-template <int DH, bool DROP, int NQ, int ST>
+// MMF_ATTN_STAMPS (build-time, measurement only; tools/attn2_bwd_stamps.py): s_memtime cycles per wave and segment of the
+// backward kernels.  0 prologue, 1 vmcnt wait, 2 barrier, 3 DMA issue, 4 S / dP products, 5 P / dS arithmetic,
+// 6 dQ^T (dQ kernel) or dV^T / dK^T (dK/dV kernel) chain, 7 epilogue, 8 HW_ID.  Every stamp drains the wave's LDS reads
+// (s_memtime returns through lgkmcnt), so the segments are attributions, not the undisturbed schedule.
+#ifdef MMF_ATTN_STAMPS
+__device__ unsigned long long* g_bstamps = nullptr;       // [kernel 0 dQ / 1 dKdV][workgroup][4 waves][12]
+#define BSTAMP(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); seg[i] += t_ - tlast; tlast = t_; } while (0)
+#define BSTAMP_DECL unsigned long long seg[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long tlast = __builtin_readcyclecounter()
+#define BSTAMP_STORE(kern) do { seg[8] = __builtin_amdgcn_s_getreg(63492); \
+    if (g_bstamps && (threadIdx.x & 63) == 0) { for (int i_ = 0; i_ < 12; ++i_) \
+      g_bstamps[(((size_t)(kern) * 65536 + blockIdx.x) * 4 + (threadIdx.x >> 6)) * 12 + i_] = seg[i_]; } } while (0)
+#else
+#define BSTAMP(i) do {} while (0)
+#define BSTAMP_DECL do {} while (0)
+#define BSTAMP_STORE(kern) do {} while (0)
+#endif
+
+// One wave of the forward: its 32-row query block at rows qs (ACTIVE), or staging and barriers only.
+template <int DH, bool DROP, bool ACTIVE>
 __device__ __forceinline__ void fwd2_wave(const AttnArgs2& a, const mmf_attn_problem& P, const int pidx, const int bh,
                                           const int qs, char* smem) {
-  constexpr int KS = DH / 16, DT = DH / 32, SB = (DH + 8) * 2, TILE_B = 64 * SB, STAGE_B = 2 * TILE_B;
-  constexpr int NQA = NQ > 0 ? NQ : 1;
+  constexpr int KS = DH / 16, DT = DH / 32, TILE_B = img_tile_bytes<DH>(), STAGE_B = 2 * TILE_B;
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int Tq = P.Tq, Tk = P.Tk, H = P.H;
@@ -38,161 +52,131 @@ __device__ __forceinline__ void fwd2_wave(const AttnArgs2& a, const mmf_attn_pro
 
   const unsigned short* Kg = static_cast<const unsigned short*>(P.K) + (size_t)b * Tk * P.ldk + h * DH;
   const unsigned short* Vg = static_cast<const unsigned short*>(P.V) + (size_t)b * Tk * P.ldv + h * DH;
-  const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(Kg), 0, Tk * P.ldk * 2, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(Vg), 0, Tk * P.ldv * 2, 0x00020000);
-
-  // ST-stage ring (ST = 2: tile j+1 in flight under tile j; ST = 3: tiles j+1 and j+2 — a single workgroup's tile of
-  // compute (~1.6 us) is shorter than a K/V DMA round trip under load, so with one tile of prefetch every tile's
-  // barrier waits for memory: a 256-CU launch of ONE problem ran 3.4 us per 64-key tile against ~1.6 us of work)
-  auto issue = [&](int j) { dma_pair<DH>(rsK, rsV, P.ldk, P.ldv, smem + (j % ST) * STAGE_B, j, wave, lane); };
+  TileDma<DH> dma;
+  dma.init(P.ldk, P.ldv, wave, lane);
+  auto issue = [&](int j) {
+    dma.issue(Kg + (size_t)64 * j * P.ldk, Vg + (size_t)64 * j * P.ldv, P.ldk, P.ldv, Tk - 64 * j, smem + (j & 1) * STAGE_B, wave);
+  };
   const int ntiles = (Tk + 63) / 64;
   issue(0);
-  if (ST > 2 && ntiles > 1) issue(1);
 
-  // Q fragments through the wave's slice of the last stage (free until the loop issues tile ST-1 behind its first barrier)
-  char* slice = smem + (ST - 1) * STAGE_B + wave * (32 * SB);
-  bf16x8_t qf[NQA][KS];
-  if constexpr (NQ > 0) {
+  // Q fragments through the wave's slice of stage 1 (free until the loop issues tile 1 behind its first barrier)
+  char* slice = smem + STAGE_B + wave * img_slice_bytes<DH>();
+  bf16x8_t qf[KS];
+  if constexpr (ACTIVE) {
     const unsigned short* Qg = static_cast<const unsigned short*>(P.Q) + (size_t)b * Tq * P.ldq + h * DH;
-#pragma unroll
-    for (int qb = 0; qb < NQ; ++qb) load_row_frags_lds<DH>(qf[qb], Qg, P.ldq, qs + 128 * qb, Tq, lane, slice);
+    const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(Qg), 0, Tq * P.ldq * 2, 0x00020000);
+    RowLoad<DH> rl;
+    rl.issue(rsQ, P.ldq, qs, lane);
+    rl.commit(qf, lane, slice);
   }
 
-  f32x16_t o[NQA][DT];
-  float m[NQA], l[NQA];
+  f32x16_t o[DT];
+  float m = NEG_BIG, l = 0.f;
 #pragma unroll
-  for (int qb = 0; qb < NQA; ++qb) {
-    m[qb] = NEG_BIG; l[qb] = 0.f;
+  for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[qb][dt][r] = 0.f;
-  }
+    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
   const float c = a.scale * LOG2E;
   const unsigned dkey = DROP ? mmf_rng_key(*a.rng_state, a.site, (unsigned)(pidx * 4096 + bh)) : 0u;
-  // this lane's part of a transposed-read address (attn_helpers.h tr_frag)
-  const unsigned troff = (unsigned)((4 * half + ((lane >> 2) & 3)) * SB + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2);
+  const unsigned tlo = tr_lane_lo(lane), thi = tr_lane_hi(lane);
   const unsigned smem_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 
-  // pieces of one tile this wave issues (dma_pair: piece p = wave + 4 i < 2 PIECES): the count a counted vmcnt leaves in flight
-  constexpr int PIECES2 = 2 * (TILE_B / 1024);
   for (int j = 0; j < ntiles; ++j) {
-    if (ST > 2 && j + 1 < ntiles) {                        // leave tile j+1's pieces in flight
-      if (wave < PIECES2 % 4) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PIECES2 / 4 + 1) : "memory");
-      else                    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PIECES2 / 4) : "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of tile j have landed
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of tile j have landed
     __builtin_amdgcn_s_barrier();                          // ... everyone's; the stage of tile j-1 is free
     asm volatile("" ::: "memory");
-    if (j + ST - 1 < ntiles && !(a.debug & 1)) issue(j + ST - 1);
-    if constexpr (NQ > 0) {
-      const char* sK = smem + (j % ST) * STAGE_B;
-      const unsigned va = smem_lds + (j % ST) * STAGE_B + TILE_B + troff;
+    if (j + 1 < ntiles) issue(j + 1);
+    if constexpr (ACTIVE) {
+      const char* sK = smem + (j & 1) * STAGE_B;
+      const TrBase vaV = tr_base(smem_lds + (j & 1) * STAGE_B + TILE_B, tlo, thi);
       const int kb = j * 64;
       // one 32-key block: S^T = K.Q^T (raw scores), online softmax (lane = query), O^T += V^T.P^T
       auto block = [&](auto KTc) {
         constexpr int KT = decltype(KTc)::value;
         const int k0 = kb + 32 * KT;
         if (k0 >= Tk) return;                              // wave-uniform: nothing but masked keys
-        f32x16_t s[NQ];
+        f32x16_t s;
 #pragma unroll
-        for (int qb = 0; qb < NQ; ++qb)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) s[qb][r] = 0.f;
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
         mfma_prio(1);
-        if constexpr (NQ == 1) {
-          // all KS fragment reads in flight before the first MFMA: one exposed LDS latency per block instead of KS / 2
-          bf16x8_t kf[KS];
+        // all KS fragment reads in flight before the first MFMA: one exposed LDS latency per block instead of KS / 2
+        bf16x8_t kf[KS];
 #pragma unroll
-          for (int ks = 0; ks < KS; ++ks) kf[ks] = row_frag<DH>(sK, 32 * KT, ks, lane);
-          __builtin_amdgcn_sched_barrier(0);               // (the scheduler otherwise re-pairs them with the MFMAs)
+        for (int ks = 0; ks < KS; ++ks) kf[ks] = row_frag<DH>(sK, 32 * KT, ks, lane);
+        __builtin_amdgcn_sched_barrier(0);                 // (the scheduler otherwise re-pairs them with the MFMAs)
 #pragma unroll
-          for (int ks = 0; ks < KS; ++ks)
-            s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[0][ks], s[0], 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);               // the asm V^T reads below are invisible to the compiler's lgkmcnt count
-        } else {
-#pragma unroll
-          for (int ks = 0; ks < KS; ++ks) {
-            const bf16x8_t kf = row_frag<DH>(sK, 32 * KT, ks, lane);
-#pragma unroll
-            for (int qb = 0; qb < NQ; ++qb)
-              s[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qb][ks], s[qb], 0, 0, 0);
-          }
-        }
+        for (int ks = 0; ks < KS; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], s, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);                 // the asm V^T reads below are invisible to the compiler's lgkmcnt count
         mfma_prio(0);
-        s16x4_t lo, hi, lo1, hi1;
-        tr_issue<DH, 2 * KT, 0>(va, lo, hi);               // the first two V^T fragments land under the softmax
-        tr_issue<DH, 2 * KT + 1 / DT, 1 % DT>(va, lo1, hi1);
-        const bool ragged = k0 + 32 > Tk;
-#pragma unroll
-        for (int qb = 0; qb < NQ; ++qb) {
-          if (ragged) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-              s[qb][r] = key < Tk ? s[qb][r] : NEG_BIG;
-            }
-          }
-          float mx = s[qb][0];
-#pragma unroll
-          for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[qb][r]);
-          mx = half_max(mx) * c;
-          if (!__all(mx <= m[qb] + DEFER)) {               // wave-uniform: raise the running maximum
-            const float mnew = fmaxf(m[qb], mx);
-            const float alpha = fast_exp2(m[qb] - mnew);
-            m[qb] = mnew;
-            l[qb] *= alpha;
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-              for (int r = 0; r < 16; ++r) o[qb][dt][r] *= alpha;
-          }
-          const float nm = -m[qb];
-          float rs = 0.f;
+        constexpr int TD = 2;                              // the first two V^T fragments land under the softmax
+        s16x4_t lo[2 * DT], hi[2 * DT];
+        PvStepD<DH, KT, TD, 0>::prime(vaV, lo, hi);
+        if (k0 + 32 > Tk) {                                // ragged block
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const float p = fast_exp2(__builtin_fmaf(s[qb][r], c, nm));
-            s[qb][r] = p;
-            rs += p;
-          }
-          l[qb] += rs;
-          if (DROP) {          // nn.MultiheadAttention(dropout=p): drop/rescale the probabilities fed to P.V only
-            const unsigned qidx = (unsigned)(qs + 128 * qb + (lane & 31)) * (unsigned)Tk;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const unsigned key = (unsigned)(k0 + (r & 3) + 8 * (r >> 2) + 4 * half);
-              s[qb][r] = mmf_keep(dkey, qidx + key, a.drop_thresh) ? s[qb][r] * a.inv_keep : 0.f;
-            }
+            const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            s[r] = key < Tk ? s[r] : NEG_BIG;
           }
         }
-        bf16x8_t pf[NQ];
-        PvStep2<DH, NQ, KT, 0>::run(va, lo, hi, lo1, hi1, s, pf, o);
+        float mx = s[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+        mx = half_max(mx) * c;
+        if (!__all(mx <= m + DEFER)) {                     // wave-uniform: raise the running maximum
+          const float mnew = fmaxf(m, mx);
+          const float alpha = fast_exp2(m - mnew);
+          m = mnew;
+          l *= alpha;
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+        }
+        const float nm = -m;
+        float rs = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float p = fast_exp2(__builtin_fmaf(s[r], c, nm));
+          s[r] = p;
+          rs += p;
+        }
+        l += rs;
+        if (DROP) {          // nn.MultiheadAttention(dropout=p): drop/rescale the probabilities fed to P.V only
+          const unsigned qidx = (unsigned)(qs + (lane & 31)) * (unsigned)Tk;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const unsigned key = (unsigned)(k0 + (r & 3) + 8 * (r >> 2) + 4 * half);
+            s[r] = mmf_keep(dkey, qidx + key, a.drop_thresh) ? s[r] * a.inv_keep : 0.f;
+          }
+        }
+        bf16x8_t pf;
+        PvStepD<DH, KT, TD, 0>::run(vaV, lo, hi, s, pf, o);
       };
       block(std::integral_constant<int, 0>{});
       block(std::integral_constant<int, 1>{});
     }
   }
 
-  if constexpr (NQ > 0) {
+  if constexpr (ACTIVE) {
     // the stage the last tile did not use is free (every wave passed the last barrier): reuse the wave's slice there
-    char* oslice = smem + (ntiles % ST) * STAGE_B + wave * (32 * SB);
+    char* oslice = smem + (ntiles & 1) * STAGE_B + wave * img_slice_bytes<DH>();
     unsigned short* Og = static_cast<unsigned short*>(P.O) + (size_t)b * Tq * P.ldo + h * DH;
-#pragma unroll
-    for (int qb = 0; qb < NQ; ++qb) {
-      const float lt = half_sum(l[qb]);
-      store_rows_lds<DH>(o[qb], 1.f / lt, Og, P.ldo, qs + 128 * qb, Tq, lane, oslice);
-      const int qrow = qs + 128 * qb + (lane & 31);
-      if (half == 0 && qrow < Tq) P.LSE[(size_t)bh * Tq + qrow] = m[qb] * LN2 + __logf(lt);
-    }
+    const float lt = half_sum(l);
+    store_rows_lds<DH>(o, 1.f / lt, Og, P.ldo, qs, Tq, lane, oslice);
+    const int qrow = qs + (lane & 31);
+    if (half == 0 && qrow < Tq) P.LSE[(size_t)bh * Tq + qrow] = m * LN2 + __logf(lt);
   }
 }
 
-template <int DH, bool DROP, int ST>
-__global__ __launch_bounds__(NT, 2)
-void attn_fwd2_kernel(const AttnArgs2 a) {
-  constexpr int STAGE_B = 2 * 64 * (DH + 8) * 2;
-  __shared__ __attribute__((aligned(1024))) char smem[ST * STAGE_B];         // ST = 3, DH = 96: 78 KiB, two workgroups per CU
+// One 32-row query block per wave (128 rows per workgroup), <= 168 registers, so THREE workgroups share a CU (3 x 48 KiB
+// of LDS) and a wave's LDS / MFMA dependency waits have two other waves on its SIMD to hide under (round 2: against two
+// blocks per wave at two workgroups per CU, 102.3 -> 91.7 us per step).
+template <int DH, bool DROP>
+__global__ __launch_bounds__(NT, 3)
+void attn_fwd2n_kernel(const AttnArgs2 a) {
+  constexpr int STAGE_B = 2 * img_tile_bytes<DH>();
+  __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE_B];
   const int bid = blockIdx.x;
   int pi = 0;
   while (pi + 1 < a.nprob && bid >= a.blk_start[pi + 1]) ++pi;
@@ -202,40 +186,13 @@ void attn_fwd2_kernel(const AttnArgs2 a) {
   const int item = (loc & 7) * n8 + (loc >> 3);
   if (item >= a.nwg[pi]) return;
   const mmf_attn_problem& P = a.p[pi];
-  const int nchunk = a.nchunk[pi], rpc = a.rpc[pi];
-  const int bh = item / nchunk, q0 = (item % nchunk) * rpc;
-  const int nb = (min(P.Tq, q0 + rpc) - q0 + 31) >> 5;      // 32-row query blocks in this chunk (1..8)
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int nq = (a.debug & 2) ? 0 : (wave < nb) + (wave + 4 < nb);   // blocks wave and wave + 4
-  const int qs = q0 + 32 * wave, pidx = a.orig[pi];
-  if (nq == 2)      fwd2_wave<DH, DROP, 2, ST>(a, P, pidx, bh, qs, smem);
-  else if (nq == 1) fwd2_wave<DH, DROP, 1, ST>(a, P, pidx, bh, qs, smem);
-  else              fwd2_wave<DH, DROP, 0, ST>(a, P, pidx, bh, qs, smem);
-}
-
-
-// Default since round 2 (MMF_ATTN_FWD_ROWS=256 selects the two-blocks-per-wave kernel above): one 32-row query block per wave (128 rows per workgroup), <= 168 registers, so
-// THREE workgroups share a CU (3 x 52 KiB of LDS) and a wave's LDS / MFMA dependency waits have two other waves on
-// its SIMD to hide under; the price is twice the K/V fragment reads and DMA per query row.
-template <int DH, bool DROP>
-__global__ __launch_bounds__(NT, 3)
-void attn_fwd2n_kernel(const AttnArgs2 a) {
-  constexpr int STAGE_B = 2 * 64 * (DH + 8) * 2;
-  __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE_B];
-  const int bid = blockIdx.x;
-  int pi = 0;
-  while (pi + 1 < a.nprob && bid >= a.blk_start[pi + 1]) ++pi;
-  const int loc = bid - a.blk_start[pi], n8 = (a.blk_start[pi + 1] - a.blk_start[pi]) >> 3;
-  const int item = (loc & 7) * n8 + (loc >> 3);
-  if (item >= a.nwg[pi]) return;
-  const mmf_attn_problem& P = a.p[pi];
   const int nchunk = a.nchunk[pi], rpc = a.rpc[pi];         // rpc <= 128 here
   const int bh = item / nchunk, q0 = (item % nchunk) * rpc;
   const int nb = (min(P.Tq, q0 + rpc) - q0 + 31) >> 5;      // 32-row query blocks in this chunk (1..4)
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int qs = q0 + 32 * wave, pidx = a.orig[pi];
-  if (wave < nb && !(a.debug & 2)) fwd2_wave<DH, DROP, 1, 2>(a, P, pidx, bh, qs, smem);
-  else                             fwd2_wave<DH, DROP, 0, 2>(a, P, pidx, bh, qs, smem);
+  if (wave < nb) fwd2_wave<DH, DROP, true>(a, P, pidx, bh, qs, smem);
+  else           fwd2_wave<DH, DROP, false>(a, P, pidx, bh, qs, smem);
 }
 
 // ================================================================================================
@@ -259,29 +216,39 @@ void attn_fwd2n_kernel(const AttnArgs2 a) {
 template <int DH, bool DROP, bool ACTIVE>
 __device__ __forceinline__ void dq2_wave(const AttnArgs2& a, const mmf_attn_problem& P, const int pidx, const int bh,
                                          const int qs, char* smem) {
-  constexpr int KS = DH / 16, DT = DH / 32, SB = (DH + 8) * 2, TILE_B = 64 * SB, STAGE_B = 2 * TILE_B;
+  constexpr int KS = DH / 16, DT = DH / 32, TILE_B = img_tile_bytes<DH>(), STAGE_B = 2 * TILE_B;
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int Tq = P.Tq, Tk = P.Tk, H = P.H;
   const int b = bh / H, h = bh % H;
   const unsigned short* Kg = static_cast<const unsigned short*>(P.K) + (size_t)b * Tk * P.ldk + h * DH;
   const unsigned short* Vg = static_cast<const unsigned short*>(P.V) + (size_t)b * Tk * P.ldv + h * DH;
-  const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(Kg), 0, Tk * P.ldk * 2, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(Vg), 0, Tk * P.ldv * 2, 0x00020000);
-  auto issue = [&](int j) { dma_pair<DH>(rsK, rsV, P.ldk, P.ldv, smem + (j & 1) * STAGE_B, j, wave, lane); };
+  TileDma<DH> dma;
+  dma.init(P.ldk, P.ldv, wave, lane);
+  auto issue = [&](int j) {
+    dma.issue(Kg + (size_t)64 * j * P.ldk, Vg + (size_t)64 * j * P.ldv, P.ldk, P.ldv, Tk - 64 * j, smem + (j & 1) * STAGE_B, wave);
+  };
   const int ntiles = (Tk + 63) / 64;
+  BSTAMP_DECL;
   issue(0);
 
   const int qrow = qs + (lane & 31);
   const size_t qoff = (size_t)b * Tq * P.ldq + h * DH, ooff = (size_t)b * Tq * P.ldo + h * DH;
-  char* slice = smem + STAGE_B + wave * (32 * SB);
+  char* slice = smem + STAGE_B + wave * img_slice_bytes<DH>();
   bf16x8_t qf[KS], dof[KS];
   float delta = 0.f, lse2 = 0.f;
   if constexpr (ACTIVE) {
-    load_row_frags_lds<DH>(qf, static_cast<const unsigned short*>(P.Q) + qoff, P.ldq, qs, Tq, lane, slice);
-    load_row_frags_lds<DH>(dof, static_cast<const unsigned short*>(P.dO) + ooff, P.ldo, qs, Tq, lane, slice);
+    auto rsrc = [&](const void* base, size_t off, int ld) {
+      return __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(static_cast<const unsigned short*>(base) + off), 0, Tq * ld * 2, 0x00020000);
+    };
+    RowLoad<DH> rq, rdo, ro;                                  // 3 x 6 loads in flight, one wait (RowLoad, attn_helpers.h)
+    rq.issue(rsrc(P.Q, qoff, P.ldq), P.ldq, qs, lane);
+    rdo.issue(rsrc(P.dO, ooff, P.ldo), P.ldo, qs, lane);
+    ro.issue(rsrc(P.O, ooff, P.ldo), P.ldo, qs, lane);
+    rq.commit(qf, lane, slice);
+    rdo.commit(dof, lane, slice);
     bf16x8_t of[KS];
-    load_row_frags_lds<DH>(of, static_cast<const unsigned short*>(P.O) + ooff, P.ldo, qs, Tq, lane, slice);
+    ro.commit(of, lane, slice);
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const u32x4_t x = __builtin_bit_cast(u32x4_t, of[ks]), y = __builtin_bit_cast(u32x4_t, dof[ks]);
@@ -300,18 +267,22 @@ __device__ __forceinline__ void dq2_wave(const AttnArgs2& a, const mmf_attn_prob
   for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) dq[0][dt][r] = 0.f;
-  const unsigned troff = (unsigned)((4 * half + ((lane >> 2) & 3)) * SB + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2);
+  const unsigned tlo = tr_lane_lo(lane), thi = tr_lane_hi(lane);
   const unsigned smem_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 
+  if constexpr (ACTIVE) BSTAMP(0);
   for (int j = 0; j < ntiles; ++j) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (ACTIVE) BSTAMP(1);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    if constexpr (ACTIVE) BSTAMP(2);
     if (j + 1 < ntiles) issue(j + 1);
+    if constexpr (ACTIVE) BSTAMP(3);
     if constexpr (ACTIVE) {
       const char* sK = smem + (j & 1) * STAGE_B;
       const char* sV = sK + TILE_B;
-      const unsigned vaK = smem_lds + (j & 1) * STAGE_B + troff;
+      const TrBase vaK = tr_base(smem_lds + (j & 1) * STAGE_B, tlo, thi);
       auto block = [&](auto KTc) {
         constexpr int KT = decltype(KTc)::value;
         const int k0 = j * 64 + 32 * KT;
@@ -326,8 +297,10 @@ __device__ __forceinline__ void dq2_wave(const AttnArgs2& a, const mmf_attn_prob
           dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<DH>(sV, 32 * KT, ks, lane), dof[ks], dp, 0, 0, 0);
         }
         mfma_prio(0);
-        s16x4_t lo, hi;
-        tr_issue<DH, 2 * KT, 0>(vaK, lo, hi);
+        BSTAMP(4);
+        constexpr int TD = MMF_DQ_TRDEPTH;
+        s16x4_t lo[2 * DT], hi[2 * DT];
+        PvStepD<DH, KT, TD, 0>::prime(vaK, lo, hi);         // the first K^T fragments land under the dS arithmetic
         const bool ragged = k0 + 32 > Tk;
         f32x16_t ds[1];
 #pragma unroll
@@ -339,23 +312,27 @@ __device__ __forceinline__ void dq2_wave(const AttnArgs2& a, const mmf_attn_prob
           if (DROP) dpv = mmf_keep(dkey, qidx + (unsigned)key, a.drop_thresh) ? dpv * a.inv_keep : 0.f;
           ds[0][r] = p * (dpv - delta);                     // dS^T (scale applied at the store)
         }
-        bf16x8_t pf[1];
-        PvStep<DH, 1, KT, 0>::run(vaK, lo, hi, ds, pf, dq);
+        BSTAMP(5);
+        bf16x8_t pf;
+        PvStepD<DH, KT, TD, 0>::run(vaK, lo, hi, ds[0], pf, dq[0]);
+        BSTAMP(6);
       };
       block(std::integral_constant<int, 0>{});
       block(std::integral_constant<int, 1>{});
     }
   }
   if constexpr (ACTIVE) {
-    char* oslice = smem + (ntiles & 1) * STAGE_B + wave * (32 * SB);
+    char* oslice = smem + (ntiles & 1) * STAGE_B + wave * img_slice_bytes<DH>();
     store_rows_lds<DH>(dq[0], a.scale, static_cast<unsigned short*>(P.dQ) + qoff, P.ldq, qs, Tq, lane, oslice);
+    BSTAMP(7);
+    BSTAMP_STORE(0);
   }
 }
 
 template <int DH, bool DROP>
 __global__ __launch_bounds__(NT, DQ_WAVES_PER_SIMD)
 void attn_bwd_dq2_kernel(const AttnArgs2 a) {
-  constexpr int STAGE_B = 2 * 64 * (DH + 8) * 2;
+  constexpr int STAGE_B = 2 * img_tile_bytes<DH>();
   __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE_B];
   const int bid = blockIdx.x;
   int pi = 0;
@@ -372,37 +349,12 @@ void attn_bwd_dq2_kernel(const AttnArgs2 a) {
   else           dq2_wave<DH, DROP, false>(a, P, pidx, bh, qs, smem);
 }
 
-// dV^T += dO^T . P and dK^T += Q^T . dS for the 32 query rows of block QS: 4 DT fragment steps alternating the
-// dO tile (va) and the Q tile (va - TILE_B... given separately), the next fragment in flight under this step's MFMA
-template <int DH, int QS, int N>
-struct DkvStep {
-  static constexpr int DT = DH / 32, NF = 4 * DT;            // step N: ss = N / (2 DT), dt = (N / 2) % DT, operand N & 1
-  static __device__ __forceinline__ void run(unsigned vaQ, unsigned vadO, s16x4_t lo, s16x4_t hi, const f32x16_t& pm,
-                                             const f32x16_t& dsm, bf16x8_t& pf, bf16x8_t& dsf,
-                                             f32x16_t (&dv)[DT], f32x16_t (&dk)[DT]) {
-    s16x4_t nlo, nhi;
-    if constexpr (N + 1 < NF) {
-      constexpr int M = N + 1;
-      tr_issue<DH, 2 * QS + M / (2 * DT), (M / 2) % DT>((M & 1) ? vaQ : vadO, nlo, nhi);
-    }
-    tr_wait<(N + 1 < NF) ? 2 : 0>(lo, hi);
-    if constexpr (N == 0) mfma_prio(1);
-    const bf16x8_t f = join(lo, hi);
-    if constexpr (N % (2 * DT) == 0) { pf = acc_frag(pm, N / (2 * DT)); dsf = acc_frag(dsm, N / (2 * DT)); }
-    constexpr int dt = (N / 2) % DT;
-    if constexpr ((N & 1) == 0) dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f, pf, dv[dt], 0, 0, 0);
-    else                        dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f, dsf, dk[dt], 0, 0, 0);
-    if constexpr (N + 1 < NF) DkvStep<DH, QS, N + 1>::run(vaQ, vadO, nlo, nhi, pm, dsm, pf, dsf, dv, dk);
-    else mfma_prio(0);
-  }
-};
-
 // Sweep split as in dq2_wave: a problem with <= 32 keys gives them to waves 0 and 1, wave w works on 32-row query
 // block w of every tile; wave 1's partial dK^T, dV^T are added to wave 0's through LDS at the end.
 template <int DH, bool DROP, bool ACTIVE>
 __device__ __forceinline__ void dkv2_wave(const AttnArgs2& a, const mmf_attn_problem& P, const int pidx, const int bh,
                                           const int k0, char* smem, const bool split_wg, const int sel) {
-  constexpr int KS = DH / 16, DT = DH / 32, SB = (DH + 8) * 2, TILE_B = 64 * SB, STAGE_B = 2 * TILE_B;
+  constexpr int KS = DH / 16, DT = DH / 32, TILE_B = img_tile_bytes<DH>(), STAGE_B = 2 * TILE_B;
   constexpr int STAT_OFF = 2 * STAGE_B;                      // [stage][lse 64 | delta 64] f32 behind the two stages
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -410,12 +362,12 @@ __device__ __forceinline__ void dkv2_wave(const AttnArgs2& a, const mmf_attn_pro
   const int b = bh / H, h = bh % H;
   const unsigned short* Qg = static_cast<const unsigned short*>(P.Q) + (size_t)b * Tq * P.ldq + h * DH;
   const unsigned short* dOg = static_cast<const unsigned short*>(P.dO) + (size_t)b * Tq * P.ldo + h * DH;
-  const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(Qg), 0, Tq * P.ldq * 2, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsdO = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(dOg), 0, Tq * P.ldo * 2, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsL = __builtin_amdgcn_make_buffer_rsrc(P.LSE + (size_t)bh * Tq, 0, Tq * 4, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc(P.delta + (size_t)bh * Tq, 0, Tq * 4, 0x00020000);
+  TileDma<DH> dma;
+  dma.init(P.ldq, P.ldo, wave, lane);
   auto issue = [&](int j) {
-    dma_pair<DH>(rsQ, rsdO, P.ldq, P.ldo, smem + (j & 1) * STAGE_B, j, wave, lane);
+    dma.issue(Qg + (size_t)64 * j * P.ldq, dOg + (size_t)64 * j * P.ldo, P.ldq, P.ldo, Tq - 64 * j, smem + (j & 1) * STAGE_B, wave);
     // LSE and delta of the tile's 64 query rows: one 256-B piece each (4 B per lane; rows past Tq read as 0,
     // which is harmless: their Q and dO rows are zeros, so P = 1 meets dO = 0 and dS = 1 * (0 - 0))
     char* st = smem + STAT_OFF + (j & 1) * 512;
@@ -423,14 +375,20 @@ __device__ __forceinline__ void dkv2_wave(const AttnArgs2& a, const mmf_attn_pro
     if (wave == 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsD, (lds_void_t*)(st + 256), 4, (unsigned)(64 * j + lane) * 4u, 0, 0, 0);
   };
   const int ntiles = (Tq + 63) / 64;
+  BSTAMP_DECL;
   issue(0);
 
   const size_t koff = (size_t)b * Tk * P.ldk + h * DH, voff = (size_t)b * Tk * P.ldv + h * DH;
-  char* slice = smem + STAGE_B + wave * (32 * SB);
+  char* slice = smem + STAGE_B + wave * img_slice_bytes<DH>();
   bf16x8_t kf[KS], vf[KS];
   if constexpr (ACTIVE) {
-    load_row_frags_lds<DH>(kf, static_cast<const unsigned short*>(P.K) + koff, P.ldk, k0, Tk, lane, slice);
-    load_row_frags_lds<DH>(vf, static_cast<const unsigned short*>(P.V) + voff, P.ldv, k0, Tk, lane, slice);
+    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(static_cast<const unsigned short*>(P.K) + koff), 0, Tk * P.ldk * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(static_cast<const unsigned short*>(P.V) + voff), 0, Tk * P.ldv * 2, 0x00020000);
+    RowLoad<DH> rk, rv;                                       // 2 x 6 loads in flight, one wait (RowLoad, attn_helpers.h)
+    rk.issue(rsK, P.ldk, k0, lane);
+    rv.issue(rsV, P.ldv, k0, lane);
+    rk.commit(kf, lane, slice);
+    rv.commit(vf, lane, slice);
   }
   f32x16_t dk[DT], dv[DT];
 #pragma unroll
@@ -440,19 +398,23 @@ __device__ __forceinline__ void dkv2_wave(const AttnArgs2& a, const mmf_attn_pro
   const float c = a.scale * LOG2E;
   const unsigned dkey = DROP ? mmf_rng_key(*a.rng_state, a.site, (unsigned)(pidx * 4096 + bh)) : 0u;
   const unsigned kcol = (unsigned)(k0 + (lane & 31));
-  const unsigned troff = (unsigned)((4 * half + ((lane >> 2) & 3)) * SB + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2);
+  const unsigned tlo = tr_lane_lo(lane), thi = tr_lane_hi(lane);
   const unsigned smem_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 
+  if constexpr (ACTIVE) BSTAMP(0);
   for (int j = 0; j < ntiles; ++j) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (ACTIVE) BSTAMP(1);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    if constexpr (ACTIVE) BSTAMP(2);
     if (j + 1 < ntiles) issue(j + 1);
+    if constexpr (ACTIVE) BSTAMP(3);
     if constexpr (ACTIVE) {
       const char* sQ = smem + (j & 1) * STAGE_B;
       const char* sdO = sQ + TILE_B;
       const float* sl = reinterpret_cast<const float*>(smem + STAT_OFF + (j & 1) * 512);
-      const unsigned vaQ = smem_lds + (j & 1) * STAGE_B + troff, vadO = vaQ + TILE_B;
+      const TrBase vaQ = tr_base(smem_lds + (j & 1) * STAGE_B, tlo, thi), vadO = tr_base(smem_lds + (j & 1) * STAGE_B + TILE_B, tlo, thi);
       auto block = [&](auto QSc) {
         constexpr int QS = decltype(QSc)::value;
         const int q0 = j * 64 + 32 * QS;
@@ -468,8 +430,10 @@ __device__ __forceinline__ void dkv2_wave(const AttnArgs2& a, const mmf_attn_pro
           dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<DH>(sdO, 32 * QS, ks, lane), vf[ks], dp, 0, 0, 0);
         }
         mfma_prio(0);
-        s16x4_t lo, hi;
-        tr_issue<DH, 2 * QS, 0>(vadO, lo, hi);
+        BSTAMP(4);
+        constexpr int TD = MMF_DKV_TRDEPTH;
+        s16x4_t lo[4 * DT], hi[4 * DT];
+        DkvStepD<DH, QS, TD, 0>::prime(vaQ, vadO, lo, hi);  // the first fragments land under the P / dS arithmetic
         f32x16_t ds;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -489,8 +453,10 @@ __device__ __forceinline__ void dkv2_wave(const AttnArgs2& a, const mmf_attn_pro
             ds[4 * g + i] = p * (dpv - d4[i]);
           }
         }
+        BSTAMP(5);
         bf16x8_t pf, dsf;
-        DkvStep<DH, QS, 0>::run(vaQ, vadO, lo, hi, s, ds, pf, dsf, dv, dk);
+        DkvStepD<DH, QS, TD, 0>::run(vaQ, vadO, lo, hi, s, ds, pf, dsf, dv, dk);
+        BSTAMP(6);
       };
       block(std::integral_constant<int, 0>{});
       block(std::integral_constant<int, 1>{});
@@ -521,16 +487,18 @@ __device__ __forceinline__ void dkv2_wave(const AttnArgs2& a, const mmf_attn_pro
   }
   if constexpr (ACTIVE) {
     if (sel > 0) return;
-    char* oslice = smem + (ntiles & 1) * STAGE_B + wave * (32 * SB);
+    char* oslice = smem + (ntiles & 1) * STAGE_B + wave * img_slice_bytes<DH>();
     store_rows_lds<DH>(dk, a.scale, static_cast<unsigned short*>(P.dK) + koff, P.ldk, k0, Tk, lane, oslice);
     store_rows_lds<DH>(dv, 1.f, static_cast<unsigned short*>(P.dV) + voff, P.ldv, k0, Tk, lane, oslice);
+    BSTAMP(7);
+    BSTAMP_STORE(1);
   }
 }
 
 template <int DH, bool DROP>
 __global__ __launch_bounds__(NT, 2)      // dK^T, dV^T, K and V fragments alone are 144 registers: two waves per SIMD
 void attn_bwd_dkv2_kernel(const AttnArgs2 a) {
-  constexpr int STAGE_B = 2 * 64 * (DH + 8) * 2;
+  constexpr int STAGE_B = 2 * img_tile_bytes<DH>();
   __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE_B + 2 * 512];
   const int bid = blockIdx.x;
   int pi = 0;
@@ -550,6 +518,12 @@ void attn_bwd_dkv2_kernel(const AttnArgs2 a) {
 }
 
 }  // namespace
+
+#ifdef MMF_ATTN_STAMPS
+extern "C" int mmf_debug_attn2_stamps(unsigned long long* buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_bstamps), &buf, sizeof(buf)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 int mmf_attn_bwd2_launch(const mmf_attn_problem* problems, int n, int head_dim, float scale, float drop_p,
                          const uint64_t* rng_state, uint32_t site, hipStream_t s) {
@@ -571,43 +545,17 @@ int mmf_attn_bwd2_launch(const mmf_attn_problem* problems, int n, int head_dim, 
   return MMF_OK;
 }
 
-// Called by mmf_attn_fwd_grouped_ex (attention.hip) after validation when the second generation is selected.
-// idx (may be NULL): the caller's problem index of problems[i] — the dropout stream id the backward kernels use
-int mmf_attn_fwd2_launch_indexed(const mmf_attn_problem* problems, const int* idx, int n, int head_dim, float scale,
-                                 float drop_p, const uint64_t* rng_state, uint32_t site, hipStream_t s) {
-  if (int rc = check_ranges("mmf_attn_fwd_grouped", problems, n)) return rc;
-  AttnArgs2 a;
-  static const int rows = [] { const char* e = getenv("MMF_ATTN_FWD_ROWS"); return (e && atoi(e) == 256) ? 256 : 128; }();   // 128 (round 2): see attn_fwd2n_kernel
-  const int total = fill_args2(a, problems, n, scale, drop_p, rng_state, site, rows, false, true);
-  if (idx)
-    for (int k = 0; k < n; ++k) a.orig[k] = (short)idx[a.orig[k]];
-  const bool dr = a.drop_thresh != 0u;
-  if (rows == 128) {
-    if (head_dim == 96) { if (dr) hipLaunchKernelGGL((attn_fwd2n_kernel<96, true>), dim3(total), dim3(NT), 0, s, a);
-                          else    hipLaunchKernelGGL((attn_fwd2n_kernel<96, false>), dim3(total), dim3(NT), 0, s, a); }
-    else                { if (dr) hipLaunchKernelGGL((attn_fwd2n_kernel<64, true>), dim3(total), dim3(NT), 0, s, a);
-                          else    hipLaunchKernelGGL((attn_fwd2n_kernel<64, false>), dim3(total), dim3(NT), 0, s, a); }
-    MMF_CHECK_LAUNCH("mmf_attn_fwd_grouped(v2n)");
-    return MMF_OK;
-  }
-  static const int stages = [] { const char* e = getenv("MMF_ATTN_FWD_STAGES"); const int v = e ? atoi(e) : 2; return v == 3 ? 3 : 2; }();   // 3 measured equal (round 2): the per-tile chain, not the DMA, is what a workgroup waits for
-  if (stages == 3) {
-    if (head_dim == 96) { if (dr) hipLaunchKernelGGL((attn_fwd2_kernel<96, true, 3>), dim3(total), dim3(NT), 0, s, a);
-                          else    hipLaunchKernelGGL((attn_fwd2_kernel<96, false, 3>), dim3(total), dim3(NT), 0, s, a); }
-    else                { if (dr) hipLaunchKernelGGL((attn_fwd2_kernel<64, true, 3>), dim3(total), dim3(NT), 0, s, a);
-                          else    hipLaunchKernelGGL((attn_fwd2_kernel<64, false, 3>), dim3(total), dim3(NT), 0, s, a); }
-  } else {
-    if (head_dim == 96) { if (dr) hipLaunchKernelGGL((attn_fwd2_kernel<96, true, 2>), dim3(total), dim3(NT), 0, s, a);
-                          else    hipLaunchKernelGGL((attn_fwd2_kernel<96, false, 2>), dim3(total), dim3(NT), 0, s, a); }
-    else                { if (dr) hipLaunchKernelGGL((attn_fwd2_kernel<64, true, 2>), dim3(total), dim3(NT), 0, s, a);
-                          else    hipLaunchKernelGGL((attn_fwd2_kernel<64, false, 2>), dim3(total), dim3(NT), 0, s, a); }
-  }
-  MMF_CHECK_LAUNCH("mmf_attn_fwd_grouped(v2)");
-  return MMF_OK;
-}
-
-// Called by mmf_attn_fwd_grouped_ex (attention.hip) after validation when the second generation is selected.
+// Called by mmf_attn_fwd_grouped_ex (attention.hip) after validation.
 int mmf_attn_fwd2_launch(const mmf_attn_problem* problems, int n, int head_dim, float scale, float drop_p,
                          const uint64_t* rng_state, uint32_t site, hipStream_t s) {
-  return mmf_attn_fwd2_launch_indexed(problems, nullptr, n, head_dim, scale, drop_p, rng_state, site, s);
+  if (int rc = check_ranges("mmf_attn_fwd_grouped", problems, n)) return rc;
+  AttnArgs2 a;
+  const int total = fill_args2(a, problems, n, scale, drop_p, rng_state, site, 128, false, true);
+  const bool dr = a.drop_thresh != 0u;
+  if (head_dim == 96) { if (dr) hipLaunchKernelGGL((attn_fwd2n_kernel<96, true>), dim3(total), dim3(NT), 0, s, a);
+                        else    hipLaunchKernelGGL((attn_fwd2n_kernel<96, false>), dim3(total), dim3(NT), 0, s, a); }
+  else                { if (dr) hipLaunchKernelGGL((attn_fwd2n_kernel<64, true>), dim3(total), dim3(NT), 0, s, a);
+                        else    hipLaunchKernelGGL((attn_fwd2n_kernel<64, false>), dim3(total), dim3(NT), 0, s, a); }
+  MMF_CHECK_LAUNCH("mmf_attn_fwd_grouped");
+  return MMF_OK;
 }

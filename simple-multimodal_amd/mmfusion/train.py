@@ -59,7 +59,9 @@ class FusedAdamW:
       * ``advance()`` — device-side (graph-capturable): one thread of ``mmf_adamw_advance`` increments the
         device-resident step counter and derives the bias corrections and, with ``set_schedule``, the OneCycle
         learning rate.  Nothing crosses the PCIe bus per step, so a captured step replays correctly however far
-        the host runs ahead.  ``self.t`` is the host's mirror of the counter (no read-back).
+        the host runs ahead.  The DEVICE counter ``step_dev`` is the source of truth: ``self.t`` is only the host's
+        running guess (a captured ``advance()`` replayed K times moves ``step_dev`` by K and ``self.t`` by one), so
+        every consumer of the step count — ``state_dict``, ``set_hparams`` — first reads it back (``sync_step``).
       * ``set_hparams(lr)`` — host-side, for a learning rate the host computes: the values go through a RING of
         pinned buffers, each guarded by an event recorded behind its copy, so a buffer is never rewritten while
         an asynchronous copy may still read it (the advisor's round-1 finding: one pinned buffer rewritten every
@@ -84,6 +86,8 @@ class FusedAdamW:
         self._ring_events = [None] * self._RING
         self._ring_pos = 0
         self.t = 0
+        self._dev_advanced = False           # an advance() was enqueued since the last read-back
+        self._captured = False               # an advance() sits in a captured graph: step_dev may move at any replay
         self._upload(self._static_hparams(lr, 1.0))
 
     def _static_hparams(self, lr: float, grad_scale: float, beta1: Optional[float] = None):
@@ -116,9 +120,20 @@ class FusedAdamW:
         self.sched.copy_(torch.tensor([1.0, max_lr, float(total_steps), pct_start, div_factor, final_div_factor,
                                        1.0 if cycle_momentum else 0.0, base_momentum, max_momentum], dtype=torch.float64))
 
+    def sync_step(self) -> int:
+        """Read the device-resident step counter back into ``self.t`` (one host sync: call at checkpoint time or
+        before a host-side ``set_hparams``, never per step).  Not callable while a stream is capturing."""
+        if self._cuda and (self._dev_advanced or self._captured) and not torch.cuda.is_current_stream_capturing():
+            self.t = int(self.step_dev.item())
+            self._dev_advanced = False
+        return self.t
+
     def advance(self) -> None:
         """Device-side step advance (graph-capturable): counter += 1, bias corrections, scheduled LR."""
         self.t += 1
+        self._dev_advanced = True
+        if self._cuda and torch.cuda.is_current_stream_capturing():
+            self._captured = True            # replays of the captured launch move step_dev without this code running
         lib.check(lib.load().mmf_adamw_advance(self.step_dev.data_ptr(), self.hparams.data_ptr(),
                                                self.sched.data_ptr(), lib.stream_ptr()))
 
@@ -126,6 +141,7 @@ class FusedAdamW:
         """Host-side step advance: upload this step's hyper-parameters (call OUTSIDE a captured graph, before
         replaying it).  Safe against host run-ahead (ring of event-guarded pinned buffers).  ``beta1``: this step's
         Adam beta1 when the schedule cycles it (``one_cycle``); the bias correction uses it, as torch's Adam does."""
+        self.sync_step()                     # graph replays of advance() moved the device counter, not self.t
         self.t += 1
         self._upload(self._static_hparams(self.lr if lr is None else lr, grad_scale, beta1))
         if self._cuda:
@@ -155,6 +171,7 @@ class FusedAdamW:
         (pass ``module.parameters()``: the order ``AdamW(module.parameters())`` numbers them in).  Tensors are
         copies on the CPU."""
         a = self.arena
+        self.sync_step()                     # the device counter is the truth (captured advance() replays)
         where = {id(p): i for i, p in enumerate(a.params)}
         state, ids = {}, []
         for j, p in enumerate(params):
@@ -202,6 +219,7 @@ class FusedAdamW:
                              "the fused kernel applies one bias correction to the whole arena")
         self.t = steps.pop() if steps else 0
         self.step_dev.fill_(self.t)
+        self._dev_advanced = False
 
 
 def save_checkpoint(path: str, module: torch.nn.Module, optimizer: Optional["FusedAdamW"] = None, *, epoch: int = 0,
