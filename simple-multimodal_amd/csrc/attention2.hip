@@ -349,13 +349,37 @@ void attn_bwd_dq2_kernel(const AttnArgs2 a) {
   else           dq2_wave<DH, DROP, false>(a, P, pidx, bh, qs, smem);
 }
 
+// Row statistics of the dK/dV kernel through the matrix pipe (round 3).  In S = Q.K^T the key is the lane and the query row
+// the accumulator register, so LSE and delta of a 32-row block are needed as 16 different values per lane.  Rounds 1-2
+// staged them in LDS and read them back with eight broadcast ds_read_b128 per block in the middle of the P / dS
+// arithmetic: four or five exposed LDS round trips per block (the "arith" segment of the stamped dK/dV kernel was 3x the
+// dQ kernel's, profiles/r03_attn_bwd_stamps.txt) and a quarter of the kernel's LDS cycles.  Instead each lane keeps the two
+// statistics of ITS OWN row (lane & 31) of the block in a register (prefetched from global memory one tile ahead) and
+// ONE MFMA per statistic spreads them into the accumulator layout as an outer product with a ones fragment:
+//     D[q][key] = sum_k A[q][k] B[k][key],  A[q][0..2] = the exact three-way bf16 split of x[q],  B[0..2][key] = 1,
+// exact in f32 (8 + 8 + 8 mantissa bits, f32 accumulate).  With D as the initial accumulator of the S (and, without
+// dropout, the dP) chain the subtraction is free:  S' = Q.K^T - LSE / scale,  p = exp2(c S');  dP' = dO.V^T - delta,
+// dS = p dP'.
+__device__ __forceinline__ bf16x8_t split3_frag(float x, bool low_half) {
+  const unsigned h = __float_as_uint(x) & 0xffff0000u;
+  const float r1 = x - __uint_as_float(h);
+  const unsigned m = __float_as_uint(r1) & 0xffff0000u;
+  const float r2 = r1 - __uint_as_float(m);
+  const unsigned l = __float_as_uint(r2) & 0xffff0000u;
+  const u32x4_t w = {low_half ? ((h >> 16) | m) : 0u, low_half ? (l >> 16) : 0u, 0u, 0u};
+  return __builtin_bit_cast(bf16x8_t, w);
+}
+__device__ __forceinline__ bf16x8_t ones3_frag(bool low_half) {
+  const u32x4_t w = {low_half ? 0x3f803f80u : 0u, low_half ? 0x00003f80u : 0u, 0u, 0u};
+  return __builtin_bit_cast(bf16x8_t, w);
+}
+
 // Sweep split as in dq2_wave: a problem with <= 32 keys gives them to waves 0 and 1, wave w works on 32-row query
 // block w of every tile; wave 1's partial dK^T, dV^T are added to wave 0's through LDS at the end.
 template <int DH, bool DROP, bool ACTIVE>
 __device__ __forceinline__ void dkv2_wave(const AttnArgs2& a, const mmf_attn_problem& P, const int pidx, const int bh,
                                           const int k0, char* smem, const bool split_wg, const int sel) {
   constexpr int KS = DH / 16, DT = DH / 32, TILE_B = img_tile_bytes<DH>(), STAGE_B = 2 * TILE_B;
-  constexpr int STAT_OFF = 2 * STAGE_B;                      // [stage][lse 64 | delta 64] f32 behind the two stages
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int Tq = P.Tq, Tk = P.Tk, H = P.H;
@@ -368,15 +392,22 @@ __device__ __forceinline__ void dkv2_wave(const AttnArgs2& a, const mmf_attn_pro
   dma.init(P.ldq, P.ldo, wave, lane);
   auto issue = [&](int j) {
     dma.issue(Qg + (size_t)64 * j * P.ldq, dOg + (size_t)64 * j * P.ldo, P.ldq, P.ldo, Tq - 64 * j, smem + (j & 1) * STAGE_B, wave);
-    // LSE and delta of the tile's 64 query rows: one 256-B piece each (4 B per lane; rows past Tq read as 0,
-    // which is harmless: their Q and dO rows are zeros, so P = 1 meets dO = 0 and dS = 1 * (0 - 0))
-    char* st = smem + STAT_OFF + (j & 1) * 512;
-    if (wave == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsL, (lds_void_t*)st, 4, (unsigned)(64 * j + lane) * 4u, 0, 0, 0);
-    if (wave == 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsD, (lds_void_t*)(st + 256), 4, (unsigned)(64 * j + lane) * 4u, 0, 0, 0);
+  };
+  // LSE and delta of this lane's row (lane & 31) of the two 32-row blocks of tile j (rows past Tq read as 0, which is
+  // harmless: their Q and dO rows are zeros, so P = 1 meets dO = 0 and dS = 1 * (0 - 0))
+  float st_l[2], st_d[2];
+  auto stats = [&](int j) {
+#pragma unroll
+    for (int qs_ = 0; qs_ < 2; ++qs_) {
+      const unsigned off = (unsigned)(64 * j + 32 * qs_ + (lane & 31)) * 4u;
+      st_l[qs_] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsL, off, 0, 0));
+      st_d[qs_] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsD, off, 0, 0));
+    }
   };
   const int ntiles = (Tq + 63) / 64;
   BSTAMP_DECL;
   issue(0);
+  if constexpr (ACTIVE) stats(0);
 
   const size_t koff = (size_t)b * Tk * P.ldk + h * DH, voff = (size_t)b * Tk * P.ldv + h * DH;
   char* slice = smem + STAGE_B + wave * img_slice_bytes<DH>();
@@ -413,17 +444,25 @@ __device__ __forceinline__ void dkv2_wave(const AttnArgs2& a, const mmf_attn_pro
     if constexpr (ACTIVE) {
       const char* sQ = smem + (j & 1) * STAGE_B;
       const char* sdO = sQ + TILE_B;
-      const float* sl = reinterpret_cast<const float*>(smem + STAT_OFF + (j & 1) * 512);
+      // this tile's row statistics as MFMA operands; the next tile's are requested now and land under this tile's work
+      const float nls = -1.f / a.scale;
+      const float cl[2] = {st_l[0] * nls, st_l[1] * nls}, cd[2] = {-st_d[0], -st_d[1]};
+      const bf16x8_t one3 = ones3_frag(half == 0);
+      if (j + 1 < ntiles) stats(j + 1);
       const TrBase vaQ = tr_base(smem_lds + (j & 1) * STAGE_B, tlo, thi), vadO = tr_base(smem_lds + (j & 1) * STAGE_B + TILE_B, tlo, thi);
       auto block = [&](auto QSc) {
         constexpr int QS = decltype(QSc)::value;
         const int q0 = j * 64 + 32 * QS;
         if (q0 >= Tq) return;
         if (sel >= 0 && QS != sel) return;                 // sweep split: this wave's half of the tile
-        f32x16_t s, dp;
+        f32x16_t s, dp, z;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+        for (int r = 0; r < 16; ++r) z[r] = 0.f;
         mfma_prio(1);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(split3_frag(cl[QS], half == 0), one3, z, 0, 0, 0);   // S' starts at -LSE / scale
+        f32x16_t dm;                                                                      // -delta[q] in every key column
+        dm = __builtin_amdgcn_mfma_f32_32x32x16_bf16(split3_frag(cd[QS], half == 0), one3, z, 0, 0, 0);
+        if constexpr (DROP) dp = z; else dp = dm;                                         // dP' starts at -delta (no dropout)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<DH>(sQ, 32 * QS, ks, lane), kf[ks], s, 0, 0, 0);
@@ -436,21 +475,16 @@ __device__ __forceinline__ void dkv2_wave(const AttnArgs2& a, const mmf_attn_pro
         DkvStepD<DH, QS, TD, 0>::prime(vaQ, vadO, lo, hi);  // the first fragments land under the P / dS arithmetic
         f32x16_t ds;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const f32x4_t l4 = *reinterpret_cast<const f32x4_t*>(sl + 32 * QS + 8 * g + 4 * half);
-          const f32x4_t d4 = *reinterpret_cast<const f32x4_t*>(sl + 64 + 32 * QS + 8 * g + 4 * half);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const float p = fast_exp2(__builtin_fmaf(s[4 * g + i], c, -l4[i] * LOG2E));
-            float pd = p, dpv = dp[4 * g + i];
-            if (DROP) {
-              const unsigned q = (unsigned)(q0 + 8 * g + 4 * half + i);
-              const bool keep = mmf_keep(dkey, q * (unsigned)Tk + kcol, a.drop_thresh);
-              pd = keep ? p * a.inv_keep : 0.f;
-              dpv = keep ? dpv * a.inv_keep : 0.f;
-            }
-            s[4 * g + i] = pd;                            // dV^T += dO^T . P_dropped
-            ds[4 * g + i] = p * (dpv - d4[i]);
+        for (int r = 0; r < 16; ++r) {
+          const float p = fast_exp2(s[r] * c);
+          if constexpr (DROP) {
+            const unsigned q = (unsigned)(q0 + (r & 3) + 8 * (r >> 2) + 4 * half);
+            const bool keep = mmf_keep(dkey, q * (unsigned)Tk + kcol, a.drop_thresh);
+            s[r] = keep ? p * a.inv_keep : 0.f;                                       // dV^T += dO^T . P_dropped
+            ds[r] = p * ((keep ? dp[r] * a.inv_keep : 0.f) + dm[r]);
+          } else {
+            s[r] = p;
+            ds[r] = p * dp[r];
           }
         }
         BSTAMP(5);
@@ -499,7 +533,7 @@ template <int DH, bool DROP>
 __global__ __launch_bounds__(NT, 2)      // dK^T, dV^T, K and V fragments alone are 144 registers: two waves per SIMD
 void attn_bwd_dkv2_kernel(const AttnArgs2 a) {
   constexpr int STAGE_B = 2 * img_tile_bytes<DH>();
-  __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE_B + 2 * 512];
+  __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE_B];
   const int bid = blockIdx.x;
   int pi = 0;
   while (pi + 1 < a.nprob && bid >= a.blk_start[pi + 1]) ++pi;

@@ -13,7 +13,7 @@ namespace {
 #define DQ_WAVES_PER_SIMD 3            // dQ kernel at <= 168 registers: three 4-wave workgroups per CU (3 x 52 KiB of LDS)
 #endif
 #ifndef MMF_DKV_TRDEPTH
-#define MMF_DKV_TRDEPTH 4              // transposed fragments in flight ahead of the dV^T / dK^T MFMA chain (DkvStepD)
+#define MMF_DKV_TRDEPTH 3              // transposed fragments in flight ahead of the dV^T / dK^T MFMA chain (DkvStepD)
 #endif
 #ifndef MMF_DQ_TRDEPTH
 #define MMF_DQ_TRDEPTH 1               // ... ahead of the dQ^T chain (PvStepD): the dQ kernel is at its 168-register budget

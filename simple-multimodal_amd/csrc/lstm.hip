@@ -21,6 +21,7 @@
 // Time-major layout inside: y is ((T+2)*B, 2H) bf16 with a zero row block in front and behind, so h_{t-1} of the first
 // step (either direction) is read from the padding and h_prev for the wgrad GEMM is a shifted VIEW of y.
 #include "mmf_internal.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -31,6 +32,7 @@ constexpr int LSTM_SPIN_LIMIT = 1 << 22;
 struct LstmArgs {
   mmf_bilstm_args p;
   int* counters;                           // [0], [1]: arrivals per direction; [2]: status (0 ok, 1 a wait timed out)
+  int spin_limit;                          // polls before a wait gives up (LSTM_SPIN_LIMIT; MMF_LSTM_SPIN_LIMIT overrides, for the test)
 };
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
@@ -51,19 +53,24 @@ __device__ __forceinline__ void grid_arrive(int* counter) {
   }
 }
 // Wait until `target` arrivals are visible, then make the peers' stores visible to every wave of this workgroup.
-// Bounded: after LSTM_SPIN_LIMIT polls the workgroup gives up (status = 1) and never waits again (dead is sticky).
-__device__ __forceinline__ void grid_wait(int* counter, int target, int* status, int& dead) {
+// Bounded: after `limit` polls the workgroup gives up — status = 1, and `dead` becomes 1 for EVERY thread of the workgroup
+// (through the LDS word `dead_s`) and stays 1: it never waits again, and from then on it writes NaN instead of its results
+// (y in the forward, dgates in the backward), so a timed-out barrier cannot produce plausible-looking numbers: the NaNs
+// reach every later time step, the projection, the loss and the gradients (ADVICE r2 / VERDICT r2 item 4c).
+__device__ __forceinline__ void grid_wait(int* counter, int target, int* status, int limit, int* dead_s, int& dead) {
   if (threadIdx.x == 0 && !dead) {
     int it = 0;
     while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       __builtin_amdgcn_s_sleep(2);
-      if (++it > LSTM_SPIN_LIMIT) { dead = 1; __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      if (++it > limit) { *dead_s = 1; __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __syncthreads();
+  dead = *reinterpret_cast<volatile int*>(dead_s);
 }
+constexpr unsigned short BF16_NAN = 0x7fc0;
 
 __device__ __forceinline__ bf16x8_t ld_frag(const unsigned short* p) {
   return __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(p));
@@ -85,6 +92,8 @@ void bilstm_fwd_kernel(const LstmArgs a) {
   const mmf_bilstm_args& P = a.p;
   const int T = P.T, B = P.B, bt = (B + 15) >> 4;
   __shared__ __attribute__((aligned(16))) float gs[4][LSTM_MAX_BT][64][4];
+  __shared__ int dead_s;
+  if (tid == 0) dead_s = 0;
 
   // resident A operand: rows (gate = wave) * H + u0 + j of W_hh, all of K
   const unsigned short* Whh = static_cast<const unsigned short*>(P.w_hh[dir]);
@@ -119,7 +128,7 @@ void bilstm_fwd_kernel(const LstmArgs a) {
         for (int q = 0; q < 4; ++q) gxv[t][q] = gx[(size_t)(time * B + b) * (8 * H) + dir * 4 * H + q * H + u];
       }
     }
-    if (s > 0) grid_wait(counter, nsl * s, a.counters + 2, dead);
+    if (s > 0) grid_wait(counter, nsl * s, a.counters + 2, a.spin_limit, &dead_s, dead);
     f32x4_t acc[LSTM_MAX_BT];
 #pragma unroll
     for (int t = 0; t < LSTM_MAX_BT; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -149,7 +158,7 @@ void bilstm_fwd_kernel(const LstmArgs a) {
         c[t] = fg * c[t] + ig * gg;
         const float h = og * tanhf_(c[t]);
         const size_t row = (size_t)(time * B + b);
-        Y[(size_t)((time + 1) * B + b) * (2 * H) + dir * H + u] = f32_to_bf16_bits(h);
+        Y[(size_t)((time + 1) * B + b) * (2 * H) + dir * H + u] = dead ? BF16_NAN : f32_to_bf16_bits(h);
         float* ga = P.gates + row * (8 * H) + dir * 4 * H + u;
         ga[0] = ig; ga[H] = fg; ga[2 * H] = gg; ga[3 * H] = og;
         P.cell[row * (2 * H) + dir * H + u] = c[t];
@@ -171,6 +180,9 @@ void bilstm_bwd_kernel(const LstmArgs a) {
   const mmf_bilstm_args& P = a.p;
   const int T = P.T, B = P.B, bt = (B + 15) >> 4;
   __shared__ __attribute__((aligned(16))) float gs[4][LSTM_MAX_BT][64][4];
+  __shared__ int dead_s;
+  if (tid == 0) dead_s = 0;
+  __syncthreads();
 
   // resident A operand: A[i = unit u0 + j][k = gate row n] = W_hh[n][u0 + j], n = wave H + 32 ks + 8 g + e
   const unsigned short* Whh = static_cast<const unsigned short*>(P.w_hh[dir]);
@@ -212,13 +224,13 @@ void bilstm_bwd_kernel(const LstmArgs a) {
         const float d_o = dh * tc * og * (1.f - og);
         dc[t] = dct * fg;
         unsigned short* dg = dG + row * (8 * H) + dir * 4 * H + u;
-        dg[0] = f32_to_bf16_bits(d_i); dg[H] = f32_to_bf16_bits(d_f);
-        dg[2 * H] = f32_to_bf16_bits(d_g); dg[3 * H] = f32_to_bf16_bits(d_o);
+        dg[0] = dead ? BF16_NAN : f32_to_bf16_bits(d_i); dg[H] = dead ? BF16_NAN : f32_to_bf16_bits(d_f);
+        dg[2 * H] = dead ? BF16_NAN : f32_to_bf16_bits(d_g); dg[3 * H] = dead ? BF16_NAN : f32_to_bf16_bits(d_o);
       }
     }
     if (s == 0) break;
     grid_arrive(counter);
-    grid_wait(counter, nsl * (T - s), a.counters + 2, dead);
+    grid_wait(counter, nsl * (T - s), a.counters + 2, a.spin_limit, &dead_s, dead);
     // dh_{prev}[unit][batch] = sum_n W_hh[n][unit] dG_t[batch][n]
     f32x4_t acc[LSTM_MAX_BT];
 #pragma unroll
@@ -294,6 +306,11 @@ int check_lstm(const char* who, const mmf_bilstm_args* p, void* ws, size_t ws_by
   return MMF_OK;
 }
 
+int lstm_spin_limit() {
+  static const int v = [] { const char* e = getenv("MMF_LSTM_SPIN_LIMIT"); const int x = e ? atoi(e) : 0; return x > 0 ? x : LSTM_SPIN_LIMIT; }();
+  return v;
+}
+
 template <typename K>
 void launch_lstm(K kernel, const LstmArgs& a, int H, hipStream_t s) {
   hipLaunchKernelGGL(kernel, dim3(8 * (H / 16)), dim3(LSTM_THREADS), 0, s, a);
@@ -307,7 +324,7 @@ extern "C" int mmf_bilstm_layer_fwd(const mmf_bilstm_args* args, void* workspace
   if (int rc = check_lstm("mmf_bilstm_layer_fwd", args, workspace, workspace_bytes, false)) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (hipMemsetAsync(workspace, 0, 64, s) != hipSuccess) MMF_FAIL(MMF_E_LAUNCH, "mmf_bilstm_layer_fwd: workspace memset failed");
-  LstmArgs a; a.p = *args; a.counters = static_cast<int*>(workspace);
+  LstmArgs a; a.p = *args; a.counters = static_cast<int*>(workspace); a.spin_limit = lstm_spin_limit();
   switch (args->H) {
     case 384: launch_lstm(bilstm_fwd_kernel<384>, a, 384, s); break;
     case 128: launch_lstm(bilstm_fwd_kernel<128>, a, 128, s); break;
@@ -321,7 +338,7 @@ extern "C" int mmf_bilstm_layer_bwd(const mmf_bilstm_args* args, void* workspace
   if (int rc = check_lstm("mmf_bilstm_layer_bwd", args, workspace, workspace_bytes, true)) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (hipMemsetAsync(workspace, 0, 64, s) != hipSuccess) MMF_FAIL(MMF_E_LAUNCH, "mmf_bilstm_layer_bwd: workspace memset failed");
-  LstmArgs a; a.p = *args; a.counters = static_cast<int*>(workspace);
+  LstmArgs a; a.p = *args; a.counters = static_cast<int*>(workspace); a.spin_limit = lstm_spin_limit();
   switch (args->H) {
     case 384: launch_lstm(bilstm_bwd_kernel<384>, a, 384, s); break;
     case 128: launch_lstm(bilstm_bwd_kernel<128>, a, 128, s); break;

@@ -131,6 +131,10 @@ def bilstm(lstm: torch.nn.LSTM, x: torch.Tensor, dropout_p: float = 0.0) -> torc
         raise ValueError("bilstm: expects nn.LSTM(batch_first=True, bidirectional=True, bias=True)")
     if not x.is_cuda:
         raise RuntimeError("mmfusion LSTM runs on the GPU only (no CPU fallback)")
+    if ops.fp32_mode():
+        # the persistent recurrence keeps W_hh as bf16 MFMA fragments; there is no f32 form of it (the bf16 GEMM
+        # wrappers used to fail on the f32 masters with an unrelated TypeError)
+        raise RuntimeError("the fp32 parity mode does not cover the BiLSTM (video encoder): run it with precision='bf16'")
     B, T, In = x.shape
     outs: List[torch.Tensor] = []
     for b0 in range(0, B, MAX_B):                                   # samples are independent: chunks of <= 64

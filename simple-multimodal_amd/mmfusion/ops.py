@@ -303,10 +303,17 @@ def _wgrad_rounds(pend: List[tuple]) -> List[List[tuple]]:
     (lazy zeroing) still runs before its accumulates."""
     rounds: List[List[tuple]] = []
     spans: List[Tuple[int, int, int]] = []               # (start, end, round) of every destination placed so far
+    def span(t: torch.Tensor) -> Tuple[int, int]:
+        # bytes the kernel may touch: for a row-strided view (a column block of a packed weight) the last row ends at
+        # (rows - 1) * ld + cols, not at numel (ADVICE r2)
+        if t.dim() == 2:
+            return t.data_ptr(), t.data_ptr() + 4 * ((t.shape[0] - 1) * t.stride(0) + t.shape[1])
+        return t.data_ptr(), t.data_ptr() + 4 * t.numel()
+
     for q in pend:
-        mine = [(q[2].data_ptr(), q[2].data_ptr() + 4 * q[2].numel())]
+        mine = [span(q[2])]
         if q[3] is not None:
-            mine.append((q[3].data_ptr(), q[3].data_ptr() + 4 * q[3].numel()))
+            mine.append(span(q[3]))
         r = 0
         for a, b in mine:
             for s0, e0, r0 in spans:

@@ -73,7 +73,15 @@ def _mha_mean_project(mha: _MHAParams, projection: nn.Linear, seq: torch.Tensor,
     rows = _as_rows(seq)
     qkv = ops.linear(rows, mha.qkv_spec().w, mha.qkv_spec().b)
     weights = None
-    if want_weights and T <= 2048 and mha.head_dim % 8 == 0:
+    if want_weights and ops.fp32_mode():
+        # fp32 parity mode: qkv holds f32 rows, which the bf16 kernel below must not read — the head-averaged
+        # softmax(q k^T / sqrt(dh)) as f32 torch arithmetic on the GPU (no gradient, like the kernel)
+        with torch.no_grad():
+            H, dh = mha.num_heads, mha.head_dim
+            q = qkv[:, :hdim].reshape(B, T, H, dh).transpose(1, 2)
+            k = qkv[:, hdim:2 * hdim].reshape(B, T, H, dh).transpose(1, 2)
+            weights = torch.softmax((q * (dh ** -0.5)) @ k.transpose(-1, -2), dim=-1).mean(dim=1)
+    elif want_weights and T <= 2048 and mha.head_dim % 8 == 0:
         from mmfusion import lib as _lib
         weights = torch.empty((B, T, T), dtype=torch.float32, device=qkv.device)
         _lib.check(_lib.load().mmf_attn_weights_mean(qkv.data_ptr(), weights.data_ptr(), B, T, mha.num_heads, mha.head_dim,
