@@ -131,6 +131,8 @@ def make_train_step(model, xs, arena, world, allreduce, rank):
 
 
 def make_step(workload, model, xs, arena):
+    ones = {}
+
     def step():
         # gradients are zeroed lazily: vectors by memset, matrices by the first wgrad GEMM of the step overwriting
         # (ParamArena.zero_grad(lazy=True); finalize_grads() zeroes any matrix no wgrad wrote)
@@ -139,11 +141,17 @@ def make_step(workload, model, xs, arena):
             x.grad = None                # input gradients are produced anew each step, not accumulated across steps
         if workload == "mult":
             out = model(*xs)
-            loss = out["fused_features"].sum()
+            fused = out["fused_features"]
+            loss = fused.sum()
+            # d(sum)/d(fused) is a tensor of ones: hand autograd a resident one instead of letting loss.backward() build it
+            # with a fill and an expand kernel per step (two graph nodes on the step's single-stream critical path)
+            if "g" not in ones:
+                ones["g"] = torch.ones_like(fused)
+            torch.autograd.backward([fused], [ones["g"]])
         else:
             out = model(*xs, compute_contrastive_loss=True)
             loss = out["fused_features"].sum() + 0.1 * sum(out["contrastive_losses"].values())
-        loss.backward()
+            loss.backward()
         arena.finalize_grads()
         return loss
     return step

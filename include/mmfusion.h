@@ -236,6 +236,17 @@ int mmf_add3_grouped(const mmf_add3_problem* problems, int num_problems, void* s
  * one pass: the gradient of a tensor the forward used n times (MulT's input rows: models/fusion_layers.py:146-158). */
 #define MMF_ADDN_MAX 8
 int mmf_addn_bf16(const void* const* xs, int n, void* y, int64_t numel, int out_f32, void* stream);
+/* several such sums in one launch (bf16 out): the three modalities' input-gradient sums at the end of MulT's backward were
+ * three launches of 6 - 18 us with graph-node gaps between them, alone on the chip in front of the deferred wgrad launch
+ * (round 3, profiles/r03_step_timeline.txt) */
+#define MMF_ADDN_GROUP_MAX 4
+typedef struct mmf_addn_problem {
+  const void* x[MMF_ADDN_MAX];
+  void* y;
+  int64_t numel;
+  int32_t n;
+} mmf_addn_problem;
+int mmf_addn_grouped(const mmf_addn_problem* problems, int num_problems, void* stream);
 /* y[b][j] = mean_t x[b][t][j]  (models/fusion_layers.py:166-168); x bf16 [B][T][d], y bf16 with
  * row stride ldy (lets the three pooled modalities land side by side = torch.cat, :171). */
 int mmf_meanpool_fwd(const void* x, void* y, int B, int T, int d, int ldy, void* stream);

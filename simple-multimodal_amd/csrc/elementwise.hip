@@ -481,6 +481,61 @@ extern "C" int mmf_addn_bf16(const void* const* xs, int n, void* y, int64_t nume
   return MMF_OK;
 }
 
+struct AddNGroupArgs { int nprob; int blk_start[MMF_ADDN_GROUP_MAX + 1]; mmf_addn_problem p[MMF_ADDN_GROUP_MAX]; };
+__global__ __launch_bounds__(EW_THREADS)
+void addn_grouped_kernel(const AddNGroupArgs a) {
+  int pi = 0;
+  while (pi + 1 < a.nprob && (int)blockIdx.x >= a.blk_start[pi + 1]) ++pi;
+  const mmf_addn_problem& P = a.p[pi];
+  const int64_t nvec = P.numel >> 3;
+  const int blk = (int)blockIdx.x - a.blk_start[pi], nblk = a.blk_start[pi + 1] - a.blk_start[pi];
+  const int64_t stride = (int64_t)nblk * EW_THREADS;
+  unsigned short* y = static_cast<unsigned short*>(P.y);
+  for (int64_t i = (int64_t)blk * EW_THREADS + threadIdx.x; i < nvec; i += stride) {
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int k = 0; k < MMF_ADDN_MAX; ++k) {
+      if (k < P.n) {
+        const u32x4_t v = *reinterpret_cast<const u32x4_t*>(static_cast<const unsigned short*>(P.x[k]) + i * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { acc[2 * e] += bf16lo(v[e]); acc[2 * e + 1] += bf16hi(v[e]); }
+      }
+    }
+    const u32x4_t o = {pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3]), pack_bf16x2(acc[4], acc[5]), pack_bf16x2(acc[6], acc[7])};
+    *reinterpret_cast<u32x4_t*>(y + i * 8) = o;
+  }
+  if (blk == 0) {
+    const int64_t t = (nvec << 3) + threadIdx.x;
+    if (t < P.numel) {
+      float s = 0.f;
+      for (int k = 0; k < P.n; ++k) s += bf16_bits_to_f32(static_cast<const unsigned short*>(P.x[k])[t]);
+      y[t] = f32_to_bf16_bits(s);
+    }
+  }
+}
+
+extern "C" int mmf_addn_grouped(const mmf_addn_problem* problems, int num_problems, void* stream) {
+  if (!problems || num_problems <= 0 || num_problems > MMF_ADDN_GROUP_MAX)
+    MMF_FAIL(MMF_E_SHAPE, "mmf_addn_grouped: num_problems=%d not in 1..%d", num_problems, MMF_ADDN_GROUP_MAX);
+  AddNGroupArgs a; a.nprob = num_problems;
+  int total = 0;
+  for (int i = 0; i < num_problems; ++i) {
+    const mmf_addn_problem& q = problems[i];
+    if (q.n < 2 || q.n > MMF_ADDN_MAX || q.numel <= 0) MMF_FAIL(MMF_E_SHAPE, "mmf_addn_grouped[%d]: n=%d (2..%d) numel=%lld", i, q.n, MMF_ADDN_MAX, (long long)q.numel);
+    for (int k = 0; k < q.n; ++k) EW_PTR_CHECK("mmf_addn_grouped", q.x[k] && mmf_aligned16(q.x[k]));
+    EW_PTR_CHECK("mmf_addn_grouped", q.y && mmf_aligned16(q.y));
+    a.blk_start[i] = total;
+    total += ew_grid(q.numel >> 3);
+    a.p[i] = q;
+  }
+  a.blk_start[num_problems] = total;
+  hipLaunchKernelGGL(addn_grouped_kernel, dim3(total), dim3(EW_THREADS), 0, static_cast<hipStream_t>(stream), a);
+  MMF_CHECK_LAUNCH("mmf_addn_grouped");
+  return MMF_OK;
+}
+
 extern "C" int mmf_dropout(const void* x, void* y, int64_t n, int is_f32, float p, const uint64_t* rng_state,
                            uint32_t site, void* stream) {
   if (n <= 0) return MMF_OK;

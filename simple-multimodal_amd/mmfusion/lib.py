@@ -24,7 +24,7 @@ SYMBOLS = (
     "mmf_version", "mmf_last_error", "mmf_device_cu_count", "mmf_gemm_grouped", "mmf_gemm_grouped_ex", "mmf_gemm_select_impl", "mmf_gemm_last_impl",
     "mmf_attn_fwd_grouped_ex", "mmf_attn_bwd_grouped_ex", "mmf_dropout", "mmf_attn_select_impl",
     "mmf_attn_fwd_grouped", "mmf_attn_bwd_grouped", "mmf_layernorm_fwd_grouped",
-    "mmf_layernorm_bwd_grouped", "mmf_layernorm_bwd_workspace_bytes", "mmf_cast_f32_to_bf16", "mmf_cast_bf16_to_f32", "mmf_cast_bf16_to_f32_scaled", "mmf_cast_f32_to_bf16_2d", "mmf_add3_bf16", "mmf_add3_grouped", "mmf_addn_bf16",
+    "mmf_layernorm_bwd_grouped", "mmf_layernorm_bwd_workspace_bytes", "mmf_cast_f32_to_bf16", "mmf_cast_bf16_to_f32", "mmf_cast_bf16_to_f32_scaled", "mmf_cast_f32_to_bf16_2d", "mmf_add3_bf16", "mmf_add3_grouped", "mmf_addn_bf16", "mmf_addn_grouped",
     "mmf_meanpool_fwd", "mmf_meanpool_bwd", "mmf_meanpool_cat_fwd", "mmf_meanpool_cat_bwd", "mmf_colsum_bf16", "mmf_colsum_grouped", "mmf_relu_bwd_bf16", "mmf_relu_bwd_mixed",
     "mmf_sqnorm_f32", "mmf_adamw_step", "mmf_adamw_advance", "mmf_skinny_linear_fwd", "mmf_skinny_linear_dgrad",
     "mmf_gat3_dense_fwd", "mmf_gat3_dense_bwd", "mmf_infonce_fwd", "mmf_infonce_bwd", "mmf_adaptive_combine_fwd",
@@ -68,6 +68,11 @@ class SkinnyProblem(C.Structure):
 SKINNY_MAX_M, SKINNY_MAX_PROBLEMS = 64, 24
 ADD3_MAX = 8
 ADDN_MAX = 8
+ADDN_GROUP_MAX = 4
+
+
+class AddNProblem(C.Structure):
+    _fields_ = [("x", C.c_void_p * 8), ("y", C.c_void_p), ("numel", C.c_int64), ("n", C.c_int32)]
 
 
 class Add3Problem(C.Structure):
@@ -130,6 +135,7 @@ def load() -> C.CDLL:
     lib.mmf_add3_bf16.argtypes = [vp, vp, vp, vp, i64, vp]
     lib.mmf_add3_grouped.argtypes = [C.POINTER(Add3Problem), i32, vp]
     lib.mmf_addn_bf16.argtypes = [C.POINTER(C.c_void_p), i32, vp, i64, i32, vp]
+    lib.mmf_addn_grouped.argtypes = [C.POINTER(AddNProblem), i32, vp]
     lib.mmf_meanpool_fwd.argtypes = [vp, vp, i32, i32, i32, i32, vp]
     lib.mmf_meanpool_bwd.argtypes = [vp, vp, i32, i32, i32, i32, vp]
     lib.mmf_meanpool_cat_fwd.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_int), i32, vp, i32, i32, i32, vp]

@@ -1036,6 +1036,57 @@ def fanout(x: torch.Tensor, n: int) -> List[torch.Tensor]:
     return list(_Fanout.apply(x, n))
 
 
+class _FanoutGroup(torch.autograd.Function):
+    """_Fanout for several tensors at once: n aliases of each of m bf16 tensors; the backward receives all m * n gradients
+    together and sums them per tensor in ONE grouped launch (mmf_addn_grouped).  MulT's three modalities' input-gradient
+    sums all complete at the end of the backward; as three nodes they were three launches with graph-node gaps between
+    them, alone on the chip in front of the deferred wgrad launch (57 us per step in round 3's timeline)."""
+
+    @staticmethod
+    def forward(ctx, n: int, *xs):
+        ctx.n, ctx.m = n, len(xs)
+        return tuple(x.view_as(x) for x in xs for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        n, m = ctx.n, ctx.m
+        outs: List[Optional[torch.Tensor]] = []
+        probs, keep = [], []
+        for i in range(m):
+            live = [g for g in gs[i * n:(i + 1) * n] if g is not None]
+            if not live:
+                outs.append(None)
+                continue
+            if len(live) == 1:
+                outs.append(live[0])
+                continue
+            if len(live) > lib.ADDN_MAX:
+                raise ValueError(f"fanout of {len(live)} uses (at most {lib.ADDN_MAX})")
+            live = [g.contiguous() if g.dtype == BF16 else cast_to_bf16(g.contiguous()) for g in live]
+            out = torch.empty_like(live[0])
+            q = lib.AddNProblem()
+            for k, g in enumerate(live):
+                q.x[k] = g.data_ptr()
+            q.y, q.numel, q.n = out.data_ptr(), out.numel(), len(live)
+            probs.append(q)
+            keep += live
+            outs.append(out)
+        for i in range(0, len(probs), lib.ADDN_GROUP_MAX):
+            chunk = probs[i:i + lib.ADDN_GROUP_MAX]
+            arr = (lib.AddNProblem * len(chunk))(*chunk)
+            lib.check(lib.load().mmf_addn_grouped(arr, len(chunk), lib.stream_ptr()))
+        return (None, *outs)
+
+
+def fanout_group(xs: Sequence[torch.Tensor], n: int) -> List[List[torch.Tensor]]:
+    """[fanout(x, n) for x in xs] whose backward sums every tensor's n gradients in one grouped launch.  Falls back to
+    per-tensor fanout when some tensor needs no gradient (or in the fp32 parity mode)."""
+    if n < 2 or n > lib.ADDN_MAX or _PRECISION == "fp32" or not all(x.requires_grad and x.dtype == BF16 for x in xs):
+        return [fanout(x, n) for x in xs]
+    flat = _FanoutGroup.apply(n, *xs)
+    return [list(flat[i * n:(i + 1) * n]) for i in range(len(xs))]
+
+
 class _MeanPoolCat(torch.autograd.Function):
     """xs: (B, T_i, d) bf16 -> (B, n*d) bf16 = cat_i mean_t x_i  (fusion_layers.py:166-171)."""
 

@@ -36,6 +36,12 @@ _BRANCH_STREAM = _os.environ.get("MMF_HIER_STREAMS", "1") != "0"   # Hierarchica
 _MULT_NESTED = _os.environ.get("MMF_MULT_NESTED", "0") == "1"      # A/B: the two groups also when MulT runs inside HierarchicalFusion
 _RECAST = _os.environ.get("MMF_RECAST_EACH_STEP", "0") == "1"        # fp32 -> bf16 weight cast in every training forward
 _MULT_STREAMS = int(_os.environ.get("MMF_MULT_STREAMS", "2"))       # MulT's cross blocks as this many concurrent groups (1, 2, 3)
+# How the two groups are cut (round 3): "modality" = by QUERY modality — {t<-a, t<-v} + the text self-attention on one
+# stream, {a<-t, a<-v, v<-t, v<-a} + the audio / video self-attentions on the other, joined only in front of the pooled
+# projections — so the self-attention section (in-projection, cores, their backward: ~400 us of single-stream,
+# partly-filled launches per step in rounds 1-2) also runs two streams wide; "size" = rounds 1-2: {t<-a, a<-v, v<-t} /
+# {t<-v, a<-t, v<-a}, joined after the cross blocks.
+_MULT_GROUPING = _os.environ.get("MMF_MULT_GROUPING", "modality")
 
 
 class _FusionBase(nn.Module):
@@ -308,48 +314,71 @@ class MultimodalTransformer(_FusionBase):
                   self.video_to_text, self.video_to_audio]
         # every modality's rows are used seven times (2 queries + their residuals, 2 key/value sources, the three-way sum
         # :156-158): fan them out so that the seven input-gradient contributions are summed by ONE kernel in backward
-        tf, af, vf = ops.fanout(t, 7), ops.fanout(a, 7), ops.fanout(v, 7)
+        tf, af, vf = ops.fanout_group([t, a, v], 7)
         qs, kvs = [tf[0], tf[1], af[0], af[1], vf[0], vf[1]], [af[2], vf[2], tf[2], vf[3], tf[3], af[3]]
         ress = [tf[4], tf[5], af[4], af[5], vf[4], vf[5]]
         Tqs, Tks = [Tt, Tt, Ta, Ta, Tv, Tv], [Ta, Tv, Tt, Tv, Tt, Ta]
         t, a, v = tf[6], af[6], vf[6]
-        if _MULT_STREAMS > 1 and (_depth == 1 or _MULT_NESTED) and t.is_cuda and not ops.fp32_mode():      # as the root module only: nested in HierarchicalFusion the
-            # branch stream already fills the holes, and a third stream measured slower (hier-seq 2.90 -> 3.24 ms)
-            # The six blocks are independent: as balanced groups on concurrent streams, one group's HBM- / latency-bound
-            # launches (attention, LayerNorm, residual adds, the partly filled last round of every GEMM launch) run
-            # beside another group's GEMMs.  Forward here; autograd replays each node's backward on its forward stream.
-            groups = {2: ([0, 3, 4], [1, 2, 5]),           # {t<-a, a<-v, v<-t} / {t<-v, a<-t, v<-a}: one query size each
-                      3: ([0, 4], [1, 5], [2, 3])}[_MULT_STREAMS]
+        mhas = [self.text_self_attn, self.audio_self_attn, self.video_self_attn]
+        streams = _MULT_STREAMS > 1 and (_depth == 1 or _MULT_NESTED) and t.is_cuda and not ops.fp32_mode()
+        # (as the root module only: nested in HierarchicalFusion the branch stream already fills the holes, and a third
+        # stream measured slower: hier-seq 2.90 -> 3.24 ms)
+
+        def run_blocks(g):
+            return _cross_blocks([blocks[i] for i in g], [qs[i] for i in g], [kvs[i] for i in g], B,
+                                 [Tqs[i] for i in g], [Tks[i] for i in g], p, [ress[i] for i in g])
+
+        if streams and _MULT_STREAMS == 2 and _MULT_GROUPING == "modality":
+            # Two independent chains up to the pooled projections: text (blocks 0, 1 -> sum -> text self-attention) on the
+            # current stream, audio + video (blocks 2..5 -> sums -> their self-attentions) on a side stream.  Autograd
+            # replays each node's backward on its forward stream, so the backward is two chains wide as well.
             main = torch.cuda.current_stream()
-            outs = [None] * 6
-            sides = []
-            for gi, g in enumerate(groups[1:]):
-                side = ops.branch_stream(1 + gi)           # stream 0 belongs to HierarchicalFusion's small branches
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    r = _cross_blocks([blocks[i] for i in g], [qs[i] for i in g], [kvs[i] for i in g], B,
-                                      [Tqs[i] for i in g], [Tks[i] for i in g], p, [ress[i] for i in g])
-                for i, x in zip(g, r):
-                    outs[i] = x
-                sides.append((side, g))
-            g = groups[0]
-            for i, x in zip(g, _cross_blocks([blocks[i] for i in g], [qs[i] for i in g], [kvs[i] for i in g], B,
-                                             [Tqs[i] for i in g], [Tks[i] for i in g], p, [ress[i] for i in g])):
-                outs[i] = x
-            for side, g in sides:
-                main.wait_stream(side)
-                for i in g:
-                    outs[i].record_stream(main)
-            t_a, t_v, a_t, a_v, v_t, v_a = outs
+            side = ops.branch_stream(1)                     # stream 0 belongs to HierarchicalFusion's small branches
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                a_t, a_v, v_t, v_a = run_blocks([2, 3, 4, 5])
+                ea, ev = ops.add3_group([(a, a_t, a_v), (v, v_t, v_a)])                    # :157-158
+                att_av = _self_attention_core(mhas[1:], [ea, ev], B, [Ta, Tv], p)
+            t_a, t_v = run_blocks([0, 1])
+            et = ops.add3_group([(t, t_a, t_v)])[0]                                        # :156
+            att = _self_attention_core(mhas[:1], [et], B, [Tt], p) + att_av
+            main.wait_stream(side)
+            for x in att_av:
+                x.record_stream(main)
         else:
-            t_a, t_v, a_t, a_v, v_t, v_a = _cross_blocks(blocks, qs, kvs, B, Tqs, Tks, p, ress)    # :146-153
-        et, ea, ev = ops.add3_group([(t, t_a, t_v), (a, a_t, a_v), (v, v_t, v_a)])         # :156-158, one launch
+            if streams:
+                # The six blocks are independent: as balanced groups on concurrent streams, one group's HBM- / latency-bound
+                # launches (attention, LayerNorm, residual adds, the partly filled last round of every GEMM launch) run
+                # beside another group's GEMMs.  Forward here; autograd replays each node's backward on its forward stream.
+                groups = {2: ([0, 3, 4], [1, 2, 5]),           # {t<-a, a<-v, v<-t} / {t<-v, a<-t, v<-a}: one query size each
+                          3: ([0, 4], [1, 5], [2, 3])}[_MULT_STREAMS]
+                main = torch.cuda.current_stream()
+                outs = [None] * 6
+                sides = []
+                for gi, g in enumerate(groups[1:]):
+                    side = ops.branch_stream(1 + gi)
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side):
+                        r = run_blocks(g)
+                    for i, x in zip(g, r):
+                        outs[i] = x
+                    sides.append((side, g))
+                g = groups[0]
+                for i, x in zip(g, run_blocks(g)):
+                    outs[i] = x
+                for side, g in sides:
+                    main.wait_stream(side)
+                    for i in g:
+                        outs[i].record_stream(main)
+                t_a, t_v, a_t, a_v, v_t, v_a = outs
+            else:
+                t_a, t_v, a_t, a_v, v_t, v_a = _cross_blocks(blocks, qs, kvs, B, Tqs, Tks, p, ress)    # :146-153
+            et, ea, ev = ops.add3_group([(t, t_a, t_v), (a, a_t, a_v), (v, v_t, v_a)])         # :156-158, one launch
+            att = _self_attention_core(mhas, [et, ea, ev], B, [Tt, Ta, Tv], p)
         # :161-168.  The self-attention outputs are only ever used through their mean over T, and the
         # out-projection is affine, so mean_t(out_proj(o_t)) == out_proj(mean_t o_t): pool the attention
         # output first and run the three out-projections on (B, d) instead of (B*T, d) rows — the same
         # arithmetic up to fp reassociation, minus 2*(Tt+Ta+Tv)*d^2 FLOP/sample forward and twice that backward.
-        mhas = [self.text_self_attn, self.audio_self_attn, self.video_self_attn]
-        att = _self_attention_core(mhas, [et, ea, ev], B, [Tt, Ta, Tv], p)
         pooled_att = ops.meanpool_cat([att[0].view(B, Tt, d), att[1].view(B, Ta, d), att[2].view(B, Tv, d)])
         pf = ops.linear_group([(x, _lin(m.out_proj), None) for x, m in zip(sops.split3(pooled_att), mhas)],
                               out_f32=True, cat=True)                           # :171 (B, 3d) f32, written in place
