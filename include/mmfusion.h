@@ -100,15 +100,7 @@ typedef struct mmf_gemm_extra {
   float dropout_p;
   const uint64_t* rng_state;
   uint32_t site;
-  /* optional stream-K workspace (round 3; NULL / 0 = every tile is one workgroup's, as before).  Caller-owned device
-   * memory, at least mmf_gemm_streamk_workspace_bytes() bytes, ZERO when first handed over and not written by anyone
-   * else afterwards; one workspace must not be used by two launches that may run concurrently (one per stream).  With it,
-   * NT / NN launches whose 256 x 256 tiling does not fill its CU rounds are dealt to the CUs by k-step units instead of by
-   * tiles (csrc/gemm4.hip): partial tiles meet in the workspace, deterministically. */
-  void* workspace;
-  uint64_t workspace_bytes;
 } mmf_gemm_extra;
-uint64_t mmf_gemm_streamk_workspace_bytes(void);
 int mmf_gemm_grouped_ex(const mmf_gemm_problem* problems, int num_problems, int layout, int epilogue,
                         int out_f32, const mmf_gemm_extra* extra, void* stream);
 

@@ -6,8 +6,7 @@
 // has >> 256 workgroups even though each problem is small).  The problem table travels by value
 // in the kernel arguments, so a launch is self-contained and hipGraph-capturable.
 //
-// Kernels: gemm2.hip (LDS-DMA ring, 256 x 128 tile: wgrad and long-K NT), gemm4.hip (256 x 256 tile, data-parallel or
-// stream-K), gemm5.hip (256 x 128, 32-deep k-step, two workgroups per CU).  Rounds 1-2 kept a first-generation 128 x 128
+// Kernels: gemm2.hip (LDS-DMA ring, 256 x 128 tile: wgrad and long-K NT), gemm4.hip (256 x 256 tile), gemm5.hip (256 x 128, 32-deep k-step, two workgroups per CU).  Rounds 1-2 kept a first-generation 128 x 128
 // register-staged kernel here and a persistent variant in gemm3.hip behind mmf_gemm_select_impl(1 / 3); round 3
 // removed them (git history has them, DESIGN.md section 5 their measurements).
 #include "mmf_internal.h"
@@ -46,7 +45,7 @@ static const int g_shortk_nn = [] { const char* e = getenv("MMF_GEMM_SHORTK_NN")
 // (profiles/r02_gemm_generations.txt: every MulT launch group x {256x128, 256x256, 256x128/32-deep} in isolation).
 static const int g_tn5 = [] { const char* e = getenv("MMF_GEMM_TN5"); return e ? atoi(e) : 0; }();   // wgrad on the 32-deep two-workgroups-per-CU kernel
 static const int g_policy = [] { const char* e = getenv("MMF_GEMM_POLICY"); return e ? atoi(e) : 2; }();
-static int auto_impl(const mmf_gemm_problem* p, int n, int layout, bool streamk_ok) {
+static int auto_impl(const mmf_gemm_problem* p, int n, int layout) {
   if (layout == MMF_GEMM_TN) return g_tn5 ? 5 : 2;
   long tiles = 0;
   int kmax = 0;
@@ -56,10 +55,6 @@ static int auto_impl(const mmf_gemm_problem* p, int n, int layout, bool streamk_
   }
   static const int cus = [] { int c = mmf_device_cu_count(); return c > 0 ? c : 256; }();
   const long rounds = (tiles + cus - 1) / cus;
-  // Round 3: with a stream-K workspace the 256 x 256 kernel deals k-step units instead of tiles, so its coarse
-  // quantisation — the reason for every other branch below — is gone: it takes every NT / NN launch that gives each CU
-  // at least four k-steps (gemm4.hip decides between its data-parallel and stream-K forms itself).
-  if (streamk_ok && g_policy >= 2 && tiles * 4 >= cus) return 4;
   if (g_policy >= 2) {
     // The 256x256 tile (1.2+ PF steady state) wins whenever its tiling either fills its CU rounds (>= 80 %) or is one
     // partial round of at least half the chip: a launch that leaves CUs idle still finishes sooner than two rounds of
@@ -116,9 +111,7 @@ extern "C" int mmf_gemm_grouped_ex(const mmf_gemm_problem* problems, int num_pro
       MMF_FAIL(MMF_E_SHAPE, "mmf_gemm_grouped_ex: MMF_EPI_DROPOUT needs rng_state and 0 <= p < 1");
   }
   int impl = gemm_impl();
-  static const int sk_on = [] { const char* e = getenv("MMF_GEMM_STREAMK"); return e ? atoi(e) : 1; }();
-  const bool streamk_ok = sk_on && !out_f32 && extra && extra->workspace && extra->workspace_bytes >= mmf_gemm_streamk_workspace_bytes();
-  if (impl == 0) impl = auto_impl(problems, num_problems, layout, streamk_ok);
+  if (impl == 0) impl = auto_impl(problems, num_problems, layout);
   if (needs_v2 && impl != 4 && impl != 5) impl = 2;   // only gemm2 / gemm4 / gemm5 have the alpha / dropout epilogue
   t_last_impl = impl;
   for (int i = 0; i < num_problems; ++i) {

@@ -20,9 +20,10 @@
 //   order     tiles go to the XCDs in granules of 32 consecutive ids (mmf_xcd_tile, mmf_internal.h);
 //   db        wgrad's fused bias gradient is one extra MFMA per (k-substep, m-tile) against an
 //             all-ones fragment — no extra LDS or HBM traffic.
+// Round 3: the kernel body is split into tile_mainloop (k-steps [kt0, kt1) of a tile) and tile_epilogue.  A stream-K form
+// built on them (k-step units dealt evenly to 256 workgroups, partial tiles meeting in a workspace) was parity-green and
+// bit-reproducible but not faster — profiles/r03_streamk_negative.txt, git history — and was taken out again.
 #include "mmf_internal.h"
-#include <algorithm>
-#include <stdlib.h>
 
 namespace {
 
@@ -44,12 +45,6 @@ struct GemmArgs {
   const unsigned long long* rng_state;
   int tile_start[MMF_GEMM_MAX_PROBLEMS + 1];
   mmf_gemm_problem p[MMF_GEMM_MAX_PROBLEMS];
-  // stream-K (gemm4_streamk_kernel): the launch's k-step units, dealt evenly to sk_wgs workgroups
-  int sk_wgs;                        // G
-  long long sk_units;                // U = sum over problems of tiles x k-steps
-  long long unit_start[MMF_GEMM_MAX_PROBLEMS + 1];
-  float* sk_slabs;                   // [G][2][256 x 256] f32 partial tiles, lane-linear
-  int* sk_counters;                  // one arrival counter per output tile; zero between launches (the last arriver resets)
 };
 
 __device__ __forceinline__ int kc_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
@@ -352,135 +347,12 @@ void gemm4_grouped_kernel(const GemmArgs args, const int total_tiles) {
   tile_epilogue<OUT_F32>(args, P, pi, m0, n0, acc, lane, wm, wn);
 }
 
-// ---- stream-K (round 3) --------------------------------------------------------------------------------------------
-// A launch of T tiles on S = one-workgroup-per-CU slots takes ceil(T / S) tile times however small T mod S is: the MulT
-// launches with 768-wide outputs are 177 - 192 tiles (69 - 75 % of ONE round of 256 CUs), the 3072-wide ones 2.5 - 2.8
-// rounds, the in-projections 2.07 rounds of the 256 x 128 kernel — 25 - 30 % of those launches is idle CUs
-// (profiles/r02_step_launches.txt).  Here the launch's k-step UNITS (sum over tiles of their K / 64 steps) are dealt evenly:
-// workgroup rho of G takes units [rho U / G, (rho + 1) U / G), i.e. the tail of one tile, whole tiles, the head of another.
-// Whole tiles go straight to the epilogue.  A partial tile's accumulators are stored lane-linearly (one f32x4 per lane and
-// MFMA tile: 1-KiB coalesced stores) into this workgroup's slab, published in the write-through form (sc1 stores, every
-// wave s_waitcnt vmcnt(0) -> barrier -> lane 0: relaxed agent fetch_add on the tile's counter; sc1 loads), and
-// the workgroup whose add came LAST (no workgroup ever waits for another: nothing can hang, no co-residency needed)
-// acquires, sums the parts in ascending rho order (all from the slabs, its own included, so the f32 sum does not depend on
-// who came last: results are bit-reproducible), runs the epilogue and resets the counter.  XCD x works on a
-// contiguous eighth of the unit range (rho = (blockIdx % 8) G/8 + blockIdx / 8), so concurrently running workgroups of an
-// XCD stay neighbours in the super-row tile order and share panels in its L2.
-__device__ __forceinline__ long long sk_bound(const int rho, const long long U, const int G) { return ((long long)rho * U) / G; }
-
-template <bool A_KR, bool B_KR, bool OUT_F32>
-__global__ __launch_bounds__(NTHREADS, 2)
-void gemm4_streamk_kernel(const GemmArgs args) {
-  __shared__ __attribute__((aligned(1024))) char smem[STAGES * STAGE_BYTES];
-  const int G = args.sk_wgs;
-  const long long U = args.sk_units;
-  const int rho = ((int)blockIdx.x & 7) * (G >> 3) + ((int)blockIdx.x >> 3);     // G is a multiple of 8
-  const long long u0 = sk_bound(rho, U, G), u1 = sk_bound(rho + 1, U, G);
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = (wave >> 2) * 128, wn = (wave & 3) * 64;
-  f32x4_t csum[TM];                                   // (TN layouts never come here; the main loop's interface wants it)
-#pragma unroll
-  for (int i = 0; i < TM; ++i) csum[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-  int pi = 0;
-  bool first_seg = true;
-  for (long long u = u0; u < u1;) {
-    while (u >= args.unit_start[pi + 1]) ++pi;
-    const mmf_gemm_problem& P = args.p[pi];
-    const int nk = (P.K + BK - 1) / BK;
-    const long long rel = u - args.unit_start[pi];
-    const int t = (int)(rel / nk), kt0 = (int)(rel % nk);
-    const int kt1 = (int)min((long long)nk, (long long)kt0 + (u1 - u));
-    int m0, n0;
-    tile_origin(P, t, m0, n0);
-
-    f32x4_t acc[TN][TM];
-#pragma unroll
-    for (int i = 0; i < TN; ++i)
-#pragma unroll
-      for (int j = 0; j < TM; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    __syncthreads();                                  // the previous segment's fragment reads (and flag read) are done
-    tile_mainloop<A_KR, B_KR>(P, m0, n0, kt0, kt1, smem, acc, csum, false, wave, lane, wm, wn);
-
-    bool finish = kt0 == 0 && kt1 == nk;              // a whole tile: straight to the epilogue
-    if (!finish) {
-      // ---- partial tile: publish, and reduce if every other part is already in
-      const long long ts = u - kt0, te = ts + nk;     // the tile's unit interval
-      int rf = (int)((ts * G) / U);                   // first workgroup (in rho order) that holds a part of it
-      while (sk_bound(rf, U, G) > ts) --rf;
-      while (sk_bound(rf + 1, U, G) <= ts) ++rf;
-      int rl = (int)(((te - 1) * G) / U);             // last
-      while (sk_bound(rl, U, G) > te - 1) --rl;
-      while (sk_bound(rl + 1, U, G) <= te - 1) ++rl;
-      const int nparts = rl - rf + 1;
-      // Hand-off in the write-through form (MI355X_MICROARCH.md, inter-workgroup visibility, first table row; one
-      // workgroup per CU, hipMalloc memory): every slab byte is stored sc1 and loaded sc1, every storing wave drains its
-      // stores, ONE lane adds to the tile's counter, the workgroup whose add returned nparts - 1 reads.  No agent-scope
-      // fence: a release would write back the whole XCD L2 (every concurrent tile's dirty C lines) once per partial tile —
-      // measured: the fenced form ran the step's NT / NN launches at 480 - 520 TF against 640 - 800 data-parallel.
-      const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc(args.sk_slabs, 0, (int)((size_t)G * 2 * BM * BN * 4), 0x00020000);
-      const unsigned soff = (unsigned)(2 * rho + (first_seg ? 0 : 1)) << 18;
-      const unsigned loff = (unsigned)((wave * TN * TM) * 256 + lane * 4) * 4u;      // [wave][tn][tm][lane] f32x4, bytes
-#pragma unroll
-      for (int i = 0; i < TN; ++i)
-#pragma unroll
-        for (int j = 0; j < TM; ++j)
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, acc[i][j]), rsS, soff + loff + (unsigned)(i * TM + j) * 1024u, 0, 16);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // EVERY storing wave drains its stores
-      __syncthreads();
-      int* counter = args.sk_counters + args.tile_start[pi] + t;
-      volatile int* flag = reinterpret_cast<volatile int*>(smem);     // the ring is idle here; ONE __shared__ object (guide)
-      if (tid == 0) {
-        const int old = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = old == nparts - 1;
-        if (last) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // clean for the next launch
-        *flag = last;
-      }
-      __syncthreads();
-      finish = *flag != 0;
-      if (finish) {
-        // sum the parts in ascending rho order, ALL from the slabs (this workgroup's own too: a second accumulator set
-        // would not fit the register file), so the f32 sum does not depend on who came last
-#pragma unroll
-        for (int i = 0; i < TN; ++i)
-#pragma unroll
-          for (int j = 0; j < TM; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        for (int r = rf; r <= rl; ++r) {
-          // workgroup r's segment on this tile is its first one iff its range starts inside the tile
-          const unsigned poff = (unsigned)(2 * r + (sk_bound(r, U, G) >= ts ? 0 : 1)) << 18;
-#pragma unroll
-          for (int i = 0; i < TN; ++i) {
-#pragma unroll
-            for (int j = 0; j < TM; ++j)
-              acc[i][j] += __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsS, poff + loff + (unsigned)(i * TM + j) * 1024u, 0, 16));
-            __builtin_amdgcn_sched_barrier(0);        // eight loads in flight at a time: all 32 would spill the accumulators
-          }
-        }
-      }
-    }
-    if (finish) tile_epilogue<OUT_F32>(args, P, pi, m0, n0, acc, lane, wm, wn);
-    u += kt1 - kt0;
-    first_seg = false;
-  }
-}
-
 template <bool A_KR, bool B_KR>
 void launch(const GemmArgs& a, int total, int out_f32, hipStream_t s) {
   if (out_f32) hipLaunchKernelGGL((gemm4_grouped_kernel<A_KR, B_KR, true>), dim3(total), dim3(NTHREADS), 0, s, a, total);
   else         hipLaunchKernelGGL((gemm4_grouped_kernel<A_KR, B_KR, false>), dim3(total), dim3(NTHREADS), 0, s, a, total);
 }
-template <bool B_KR>
-void launch_sk(const GemmArgs& a, hipStream_t s) {      // bf16 outputs only (the f32-output form spills registers)
-  hipLaunchKernelGGL((gemm4_streamk_kernel<false, B_KR, false>), dim3(a.sk_wgs), dim3(NTHREADS), 0, s, a);
-}
-
 }  // namespace
-
-// stream-K workspace: [SK_MAX_TILES arrival counters][G x 2 slabs of 256 x 256 f32], G <= SK_MAX_WGS
-constexpr int SK_MAX_WGS = 256, SK_MAX_TILES = 16384;
-constexpr size_t SK_COUNTER_BYTES = (size_t)SK_MAX_TILES * 4, SK_SLAB_BYTES = (size_t)BM * BN * 4;
-extern "C" uint64_t mmf_gemm_streamk_workspace_bytes(void) { return SK_COUNTER_BYTES + (size_t)SK_MAX_WGS * 2 * SK_SLAB_BYTES; }
 
 // called by mmf_gemm_grouped (gemm.hip) after validation
 int mmf_gemm4_launch(const mmf_gemm_problem* problems, int num_problems, int layout, int epilogue,
@@ -494,7 +366,6 @@ int mmf_gemm4_launch(const mmf_gemm_problem* problems, int num_problems, int lay
   a.site = extra ? extra->site : 0u;
   a.rng_state = extra ? reinterpret_cast<const unsigned long long*>(extra->rng_state) : nullptr;
   int total = 0;
-  long long units = 0;
   for (int i = 0; i < num_problems; ++i) {
     const mmf_gemm_problem& p = problems[i];
     // 32-bit byte offsets inside the buffer descriptors
@@ -503,36 +374,10 @@ int mmf_gemm4_launch(const mmf_gemm_problem* problems, int num_problems, int lay
     if (a_bytes >= 0x7fffffffull || b_bytes >= 0x7fffffffull)
       MMF_FAIL(MMF_E_UNSUPPORTED, "mmf_gemm_grouped[%d]: operand larger than 2 GiB", i);
     a.tile_start[i] = total;
-    a.unit_start[i] = units;
-    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    total += tiles;
-    units += (long long)tiles * ((p.K + BK - 1) / BK);
+    total += ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     a.p[i] = p;
   }
   a.tile_start[num_problems] = total;
-  a.unit_start[num_problems] = units;
-  a.sk_wgs = 0; a.sk_units = units; a.sk_slabs = nullptr; a.sk_counters = nullptr;
-  // stream-K when the tile count does not fill its rounds of one workgroup per CU (MMF_GEMM_STREAMK=0: never;
-  // MMF_GEMM_STREAMK_FILL: the fill, in percent, under which it is used, default 92)
-  static const int sk_on = [] { const char* e = getenv("MMF_GEMM_STREAMK"); return e ? atoi(e) : 1; }();
-  static const int sk_fill = [] { const char* e = getenv("MMF_GEMM_STREAMK_FILL"); return e ? atoi(e) : 92; }();
-  if (sk_on && layout != MMF_GEMM_TN && !out_f32 && extra && extra->workspace && extra->workspace_bytes >= mmf_gemm_streamk_workspace_bytes() &&
-      total <= SK_MAX_TILES) {
-    const int cus = std::min(SK_MAX_WGS, (mmf_device_cu_count() / 8) * 8);
-    const long long rounds = (total + cus - 1) / cus;
-    // at least four k-steps per workgroup: a launch with fewer units than 4 x CUs uses fewer workgroups
-    const int G = (int)std::min<long long>(cus, (units / 4 / 8) * 8);
-    if (G >= 8 && (long long)total * 100 < rounds * cus * sk_fill) {
-      a.sk_wgs = G;
-      a.sk_counters = static_cast<int*>(extra->workspace);
-      a.sk_slabs = reinterpret_cast<float*>(static_cast<char*>(extra->workspace) + SK_COUNTER_BYTES);
-    }
-  }
-  if (a.sk_wgs) {
-    if (layout == MMF_GEMM_NT) launch_sk<false>(a, s); else launch_sk<true>(a, s);
-    MMF_CHECK_LAUNCH("mmf_gemm_grouped(v4, stream-K)");
-    return MMF_OK;
-  }
   switch (layout) {
     case MMF_GEMM_NT: launch<false, false>(a, total, out_f32, s); break;
     case MMF_GEMM_NN: launch<false, true>(a, total, out_f32, s); break;

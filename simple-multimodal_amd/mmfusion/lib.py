@@ -21,7 +21,7 @@ GEMM_MAX_PROBLEMS, ATTN_MAX_PROBLEMS, LN_MAX_PROBLEMS, COLSUM_MAX_PROBLEMS = 48,
 
 # every symbol include/mmfusion.h declares (tests check the .so exports all of them)
 SYMBOLS = (
-    "mmf_version", "mmf_last_error", "mmf_device_cu_count", "mmf_gemm_grouped", "mmf_gemm_grouped_ex", "mmf_gemm_streamk_workspace_bytes", "mmf_gemm_select_impl", "mmf_gemm_last_impl",
+    "mmf_version", "mmf_last_error", "mmf_device_cu_count", "mmf_gemm_grouped", "mmf_gemm_grouped_ex", "mmf_gemm_select_impl", "mmf_gemm_last_impl",
     "mmf_attn_fwd_grouped_ex", "mmf_attn_bwd_grouped_ex", "mmf_dropout", "mmf_attn_select_impl",
     "mmf_attn_fwd_grouped", "mmf_attn_bwd_grouped", "mmf_layernorm_fwd_grouped",
     "mmf_layernorm_bwd_grouped", "mmf_layernorm_bwd_workspace_bytes", "mmf_cast_f32_to_bf16", "mmf_cast_bf16_to_f32", "mmf_cast_bf16_to_f32_scaled", "mmf_cast_f32_to_bf16_2d", "mmf_add3_bf16", "mmf_add3_grouped", "mmf_addn_bf16", "mmf_addn_grouped",
@@ -56,8 +56,7 @@ class LnProblem(C.Structure):
 
 
 class GemmExtra(C.Structure):
-    _fields_ = [("alpha", C.c_float), ("dropout_p", C.c_float), ("rng_state", C.c_void_p), ("site", C.c_uint32),
-                ("workspace", C.c_void_p), ("workspace_bytes", C.c_uint64)]
+    _fields_ = [("alpha", C.c_float), ("dropout_p", C.c_float), ("rng_state", C.c_void_p), ("site", C.c_uint32)]
 
 
 class SkinnyProblem(C.Structure):
@@ -119,8 +118,6 @@ def load() -> C.CDLL:
     vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
     lib.mmf_gemm_grouped.argtypes = [C.POINTER(GemmProblem), i32, i32, i32, i32, vp]
     lib.mmf_gemm_grouped_ex.argtypes = [C.POINTER(GemmProblem), i32, i32, i32, i32, C.POINTER(GemmExtra), vp]
-    lib.mmf_gemm_streamk_workspace_bytes.argtypes = []
-    lib.mmf_gemm_streamk_workspace_bytes.restype = C.c_uint64
     lib.mmf_attn_fwd_grouped_ex.argtypes = [C.POINTER(AttnProblem), i32, i32, f32, f32, vp, C.c_uint32, vp]
     lib.mmf_attn_bwd_grouped_ex.argtypes = [C.POINTER(AttnProblem), i32, i32, f32, f32, vp, C.c_uint32, vp]
     lib.mmf_dropout.argtypes = [vp, vp, i64, i32, f32, vp, C.c_uint32, vp]
@@ -226,19 +223,15 @@ class _Timed:
 
 
 def gemm_grouped(problems: Sequence[GemmProblem], layout: int, epilogue: int, out_f32: bool,
-                 alpha: float = 1.0, dropout_p: float = 0.0, rng_state_ptr: Optional[int] = None, site: int = 0,
-                 workspace: Optional[tuple] = None) -> None:
-    """workspace: (device pointer, bytes) of a zero-initialised stream-K workspace owned by the caller and used by no launch
-    that may run concurrently with this one (mmfusion.ops keeps one per stream role), or None."""
+                 alpha: float = 1.0, dropout_p: float = 0.0, rng_state_ptr: Optional[int] = None, site: int = 0) -> None:
     arr = (GemmProblem * len(problems))(*problems)
     flops = sum(2.0 * p.M * p.N * p.K for p in problems) if PROFILE is not None else 0.0
     detail = [(p.M, p.N, p.K) for p in problems] if PROFILE is not None else None
     with _Timed(f"gemm_grouped_kernel<{_LAYOUT_NAME[layout]},{'f32' if out_f32 else 'bf16'}>", flops, detail) as tm:
-        if alpha == 1.0 and not (epilogue & EPI_DROPOUT) and workspace is None:
+        if alpha == 1.0 and not (epilogue & EPI_DROPOUT):
             check(load().mmf_gemm_grouped(arr, len(problems), layout, epilogue, int(out_f32), stream_ptr()))
         else:
-            ws_ptr, ws_bytes = workspace if workspace is not None else (None, 0)
-            ex = GemmExtra(alpha, dropout_p, rng_state_ptr, site, ws_ptr, ws_bytes)
+            ex = GemmExtra(alpha, dropout_p, rng_state_ptr, site)
             check(load().mmf_gemm_grouped_ex(arr, len(problems), layout, epilogue, int(out_f32), C.byref(ex), stream_ptr()))
         if PROFILE is not None:            # name the kernel generation that ran: the dominant kernel is a kernel symbol
             tm.label = f"gemm{load().mmf_gemm_last_impl()}_grouped_kernel<{_LAYOUT_NAME[layout]},{'f32' if out_f32 else 'bf16'}>"

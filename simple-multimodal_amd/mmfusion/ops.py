@@ -166,49 +166,14 @@ def gemm_group(layout: int, probs: Sequence[tuple], epilogue: int, alpha: float 
                               bias.data_ptr() if bias is not None else None,
                               aux.data_ptr() if aux is not None else None,
                               M, N, K, _ld(A), _ld(Bm), _ld(Cm), _ld(aux) if aux is not None else 0))
-    ws = streamk_workspace(probs[0][2].device) if layout != GEMM_TN else None
     if dropout is not None:
         if len(ps) > lib.GEMM_MAX_PROBLEMS:
             raise ValueError("a dropout GEMM group must fit one launch (the problem index keys the mask)")
         lib.gemm_grouped(ps, layout, epilogue | EPI_DROPOUT, out_f32, alpha, dropout[0],
-                         rng_state().data_ptr(), dropout[1], workspace=ws)
+                         rng_state().data_ptr(), dropout[1])
         return
     for i in range(0, len(ps), lib.GEMM_MAX_PROBLEMS):
-        lib.gemm_grouped(ps[i:i + lib.GEMM_MAX_PROBLEMS], layout, epilogue, out_f32, alpha, workspace=ws)
-
-
-# --------------------------------------------------------------------------------------------
-# stream-K workspaces (csrc/gemm4.hip): partial output tiles of a launch meet in caller-owned memory.  Two launches that may
-# run concurrently must not share one, and launches only run concurrently on different streams of this module's own set
-# (the current stream and ops.branch_stream(i)), so there is one workspace per stream ROLE: slot 0 for whatever stream is
-# current outside the branch streams (eager, torch's capture stream, the DP parts), slot 1 + i for branch stream i.  Keyed
-# by role, not by stream handle, a graph captured on torch's capture stream reuses the workspace the eager warm-up steps
-# allocated.  A slot is allocated (zeroed) on first use OUTSIDE a capture; a capture that meets an unallocated slot runs
-# that launch without stream-K rather than allocating from the graph's private pool.
-# --------------------------------------------------------------------------------------------
-_sk_ws: dict = {}
-
-
-def streamk_workspace(device) -> Optional[tuple]:
-    import os
-    if os.environ.get("MMF_GEMM_STREAMK", "1") == "0":
-        return None
-    cur = torch.cuda.current_stream(device)
-    slot = 0
-    for i, st in enumerate(_branch_streams):
-        if st == cur:
-            slot = 1 + i
-            break
-    key = (device.index if device.index is not None else torch.cuda.current_device(), slot)
-    t = _sk_ws.get(key)
-    if t is None:
-        if torch.cuda.is_current_stream_capturing():
-            return None
-        nbytes = int(lib.load().mmf_gemm_streamk_workspace_bytes())
-        t = torch.zeros(nbytes // 4, dtype=torch.int32, device=device)
-        torch.cuda.current_stream(device).synchronize()      # zeroed before any other stream's launch may use the slot
-        _sk_ws[key] = t
-    return t.data_ptr(), t.numel() * 4
+        lib.gemm_grouped(ps[i:i + lib.GEMM_MAX_PROBLEMS], layout, epilogue, out_f32, alpha)
 
 
 # --------------------------------------------------------------------------------------------

@@ -8,7 +8,7 @@ from mmfusion.lib import GEMM_NT, GEMM_NN
 from gemm_bench import bench
 L = lib.load()
 for (M, N) in [(8192, 3072), (8192, 768), (8192, 2048)]:
-    for impl in (2, 3):
+    for impl in (2, 4):
         lib.check(L.mmf_gemm_select_impl(impl))
         row = []
         for K in (64, 128, 256, 512, 768, 1536, 3072, 6144):
