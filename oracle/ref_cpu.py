@@ -395,22 +395,38 @@ def adaptive_fusion(P: Params, pre: str, text: Tensor, audio: Tensor, video: Ten
 def hierarchical_fusion(P: Params, pre: str, text: Tensor, audio: Tensor, video: Tensor, *,
                         num_heads: int, graph_num_layers: int, temperature: float,
                         compute_contrastive_loss: bool = False,
-                        mult_inputs: Optional[Tuple[Tensor, Tensor, Tensor]] = None
+                        mult_inputs: Optional[Tuple[Tensor, Tensor, Tensor]] = None,
+                        unit_masks: Optional[Dict[str, Tensor]] = None
                         ) -> Dict[str, Tensor]:
     """``mult_inputs`` is the build-defined *hier-seq* composition:
     when given, the MulT branch consumes those (B,T,d) sequences while the other four
     branches consume the (B,d) tensors.  With ``mult_inputs=None`` this is the literal
-    reference semantics (*hier-ref*)."""
+    reference semantics (*hier-ref*).  ``unit_masks`` (parity instrument, tests/test_configs_gpu.py): 0/1 masks by
+    output key applied to the four ReLU-terminated branch outputs before they are returned and concatenated, the same
+    masks the HIP module takes through ``HierarchicalFusion.unit_masks`` — units whose ReLU state differs between the
+    two sides are switched off on both, so the gradients can be compared tightly.  Key ``meta_hidden`` masks the meta
+    MLP's hidden layer the same way; ``capture`` (a dict) receives that hidden layer."""
     early = early_fusion(P, pre + "early_fusion.", text, audio, video)
     mi = mult_inputs if mult_inputs is not None else (text, audio, video)
-    mult = multimodal_transformer(P, pre + "mult_fusion.", *mi, num_heads)
+    mult = dict(multimodal_transformer(P, pre + "mult_fusion.", *mi, num_heads))
     graph = graph_fusion(P, pre + "graph_fusion.", text, audio, video, graph_num_layers)
-    con = contrastive_fusion(P, pre + "contrastive_fusion.", text, audio, video, temperature,
-                             compute_contrastive_loss)
-    ada = adaptive_fusion(P, pre + "adaptive_fusion.", text, audio, video, num_heads)
+    con = dict(contrastive_fusion(P, pre + "contrastive_fusion.", text, audio, video, temperature,
+                                  compute_contrastive_loss))
+    ada = dict(adaptive_fusion(P, pre + "adaptive_fusion.", text, audio, video, num_heads))
+    if unit_masks:
+        um = unit_masks
+        early = early * um["early_features"] if "early_features" in um else early
+        for dct, key in ((mult, "mult_features"), (con, "contrastive_features"), (ada, "adaptive_features")):
+            if key in um:
+                dct["fused_features"] = dct["fused_features"] * um[key]
     allf = _st(torch.cat([early, mult["fused_features"], graph, con["fused_features"],
                           ada["fused_features"]], dim=-1))                  # :503-506
     h = _st(torch.relu(linear(allf, P[pre + "meta_fusion.0.weight"], P[pre + "meta_fusion.0.bias"])))
+    if unit_masks:
+        if "capture" in unit_masks:
+            unit_masks["capture"]["meta_hidden"] = h.detach()       # (B, 2d): the meta MLP's hidden ReLU layer
+        if "meta_hidden" in unit_masks:
+            h = h * unit_masks["meta_hidden"]
     final = linear(h, P[pre + "meta_fusion.3.weight"], P[pre + "meta_fusion.3.bias"])
     return {"fused_features": final, "early_features": early,
             "mult_features": mult["fused_features"], "graph_features": graph,

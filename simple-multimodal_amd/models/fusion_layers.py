@@ -600,9 +600,24 @@ class HierarchicalFusion(_FusionBase):
             graph = self.graph_fusion(text_features, audio_features, video_features)
             con = self.contrastive_fusion(text_features, audio_features, video_features, compute_contrastive_loss)
             ada = self.adaptive_fusion(text_features, audio_features, video_features)
+        um = getattr(self, "unit_masks", None)
+        if um:
+            # parity instrument (tests/test_configs_gpu.py, oracle.ref_cpu.hierarchical_fusion(unit_masks=...)): 0/1 masks
+            # on the four ReLU-terminated branch outputs, so that the few top-level units whose ReLU state differs from
+            # the bf16-storage oracle's (pre-activations within a rounding error of zero) are off on BOTH sides
+            mult, con, ada = dict(mult), dict(con), dict(ada)
+            early = early * um["early_features"] if "early_features" in um else early
+            for dct, key in ((mult, "mult_features"), (con, "contrastive_features"), (ada, "adaptive_features")):
+                if key in um:
+                    dct["fused_features"] = dct["fused_features"] * um[key]
         allf = _as_rows(torch.cat([early, mult["fused_features"], graph, con["fused_features"],
                                    ada["fused_features"]], dim=-1))                    # :503-506
         h = ops.dropout(ops.linear(allf, *_wb(self.meta_fusion[0]), relu=True), p, True)
+        if um:
+            if "capture" in um:
+                um["capture"]["meta_hidden"] = h.detach()
+            if "meta_hidden" in um:
+                h = h * um["meta_hidden"].to(h.dtype)
         final = ops.linear(h, *_wb(self.meta_fusion[3]), out_f32=True)
         return {"fused_features": final, "early_features": early, "mult_features": mult["fused_features"],
                 "graph_features": graph, "contrastive_features": con["fused_features"],

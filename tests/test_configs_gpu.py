@@ -36,12 +36,12 @@ def _hier_cfg(d, H, G, L):
     return cfg
 
 
-def _oracle_hier_seq(cfg, P, xs):
+def _oracle_hier_seq(cfg, P, xs, unit_masks=None):
     # (bf16-storage mode: the HIP path pools the bf16 rows and stores the means as bf16; no-ops in fp32 mode)
     pooled = [ref_cpu._st(ref_cpu._st(x).mean(dim=1)) for x in xs]
     return ref_cpu.hierarchical_fusion(P, "", *pooled, num_heads=cfg.fusion_num_heads,
                                        graph_num_layers=cfg.graph_num_layers, temperature=cfg.contrastive_temperature,
-                                       compute_contrastive_loss=True, mult_inputs=tuple(xs))
+                                       compute_contrastive_loss=True, mult_inputs=tuple(xs), unit_masks=unit_masks)
 
 
 HIER_KEYS = ["fused_features", "early_features", "mult_features", "graph_features", "contrastive_features",
@@ -66,13 +66,16 @@ def test_hier_seq_matches_oracle(name, B, Ts, d, H):
     synth.probe_loss(ref).backward()
     Pb = {k: v.detach().clone().requires_grad_(True) for k, v in P.items()}
     xb = [x.clone().requires_grad_(True) for x in xs]
+    cap_ref, cap_hip = {}, {}
     with ref_cpu.bf16_storage():                            # the same arithmetic with bf16 storage
-        ref_b = _oracle_hier_seq(cfg, Pb, xb)
+        ref_b = _oracle_hier_seq(cfg, Pb, xb, unit_masks={"capture": cap_ref})
         synth.probe_loss(ref_b).backward()
 
     m = m.cuda().eval()
     xg = [x.cuda().requires_grad_(True) for x in xs]
+    m.unit_masks = {"capture": cap_hip}
     out = m(*xg, compute_contrastive_loss=True)
+    m.unit_masks = None
     synth.probe_loss(out).backward()
     torch.cuda.synchronize()
     assert set(out) == set(ref)
@@ -97,34 +100,82 @@ def test_hier_seq_matches_oracle(name, B, Ts, d, H):
         got = params[pn].grad.detach().float().cpu()
         tol = GP_L2_RELU if any(t in pn for t in RELU_FED) else GP_L2
         assert l2_rel(got, want) <= tol, f"{name}: param grad {pn} rel L2 {l2_rel(got, want):.3e} > {tol}"
-    # Against the bf16-storage oracle.  At the small size the two agree to <= 7e-3 (measured) and 2e-2 is asserted.  At
-    # the config-3 size every branch output sits behind a ReLU over only B x d = 12,288 units (B x 2d for the hidden
-    # layers): the (B, d)-row branches still agree to 1e-7 ... 6e-5, but MulT's pooled features differ by ~1e-3 (one-ulp
-    # flips of bf16 roundings averaged over T = 512), a handful of those top-level units land on the other side of
-    # zero, and ONE such unit moves every upstream gradient by ~1.3e-2 — so the gradient bound there is half the fp32
-    # one, and the forward is held tightly instead.
+    # ---- against the bf16-storage oracle, flip-aware.  Every branch output sits behind a ReLU over only
+    # B x d units; at the config-3 size MulT's pooled features differ from the oracle's by ~1e-3 (one-ulp flips of bf16
+    # roundings averaged over T = 512), so a handful of top-level units whose pre-activation is within that of zero are on
+    # in one and off in the other, and ONE such unit moves every upstream gradient by ~1.3e-2.  Round 2 halved the fp32
+    # bound for this; now the flips are COUNTED (they must be few) and those units are switched off on both sides
+    # (HierarchicalFusion.unit_masks / hierarchical_fusion(unit_masks=...): the four ReLU-terminated branch outputs and the
+    # meta MLP's hidden layer), after which the gradients must agree to the same 2e-2 as at the small size.
     from test_parity_gpu import GIN_L2_BF16, GP_L2_BF16, OUT_BF16
-    tight = name == "small"
-    gin_tol, gp_tol = (GIN_L2_BF16, GP_L2_BF16) if tight else (GIN_L2 / 2, GP_L2 / 2)
     for k in HIER_KEYS:
         if k == "attention_weights":
             continue
         want = ref_b[k].detach()
         assert l2_rel(out[k], want) <= OUT_BF16, f"{name}: {k} vs bf16-storage oracle rel L2 {l2_rel(out[k], want):.3e}"
-    for i, (g, r) in enumerate(zip(xg, xb)):
-        assert l2_rel(g.grad, r.grad) <= gin_tol, f"{name}: input grad {i} vs bf16-storage oracle {l2_rel(g.grad, r.grad):.3e}"
-    scale = max(float(v.grad.norm()) for v in Pb.values() if v.grad is not None)
+    relu_out = ["early_features", "mult_features", "contrastive_features", "adaptive_features"]
+    agree = {k: ((out[k].detach().float().cpu() > 0) == (ref_b[k].detach() > 0)).float() for k in relu_out}
+    agree["meta_hidden"] = ((cap_hip["meta_hidden"].float().cpu() > 0) == (cap_ref["meta_hidden"] > 0)).float()
+    nflip = sum(int((1 - a).sum()) for a in agree.values())
+    nunit = sum(a.numel() for a in agree.values())
+    print(f"hier-seq {name}: {nflip} of {nunit} top-level ReLU units differ in state from the bf16-storage oracle")
+    assert nflip <= max(2, int(3e-3 * nunit)), f"{name}: {nflip} of {nunit} top-level ReLU units flipped"      # measured 0.05 % (config 3)
+    Pm = {k: v.detach().clone().requires_grad_(True) for k, v in P.items()}
+    xm = [x.clone().requires_grad_(True) for x in xs]
+    with ref_cpu.bf16_storage():
+        ref_m = _oracle_hier_seq(cfg, Pm, xm, unit_masks=agree)
+        synth.probe_loss(ref_m).backward()
+    m.unit_masks = {k: a.cuda() for k, a in agree.items()}
+    for p_ in m.parameters():
+        p_.grad.zero_()
+    xg2 = [x.cuda().requires_grad_(True) for x in xs]
+    synth.probe_loss(m(*xg2, compute_contrastive_loss=True)).backward()
+    torch.cuda.synchronize()
+    m.unit_masks = None
+    for i, (g, r) in enumerate(zip(xg2, xm)):
+        assert l2_rel(g.grad, r.grad) <= GIN_L2_BF16, f"{name}: input grad {i} vs bf16-storage oracle (flipped units off) {l2_rel(g.grad, r.grad):.3e}"
+    scale = max(float(v.grad.norm()) for v in Pm.values() if v.grad is not None)
     worst = ("", 0.0)
-    for pn, p in params.items():
-        want = Pb[pn].grad
+    for pn, p_ in params.items():
+        want = Pm[pn].grad
         if want is None or float(want.norm()) <= 1e-6 * scale:      # e.g. the attention vectors of a saturated GAT softmax
-            assert float(p.grad.norm()) <= 1e-4 * scale, f"{name}: {pn} should have a (near-)zero gradient"
+            assert float(p_.grad.norm()) <= 1e-4 * scale, f"{name}: {pn} should have a (near-)zero gradient"
             continue
-        e = l2_rel(p.grad.detach().float().cpu(), want)
+        e = l2_rel(p_.grad.detach().float().cpu(), want)
         worst = max(worst, (pn, e), key=lambda t: t[1])
-        tol = 6e-2 if pn.endswith("att_dst") or pn.endswith("att_src") else gp_tol
-        assert e <= tol, f"{name}: param grad {pn} vs bf16-storage oracle {e:.3e}"
+        tol = 6e-2 if pn.endswith("att_dst") or pn.endswith("att_src") else GP_L2_BF16
+        assert e <= tol, f"{name}: param grad {pn} vs bf16-storage oracle (flipped units off) {e:.3e}"
     print(f"hier-seq {name}: worst parameter gradient vs bf16-storage oracle {worst[1]:.3e} ({worst[0]})")
+    # ---- the fp32-storage mode against the fp32 oracle at this size: the excuse-free check of the composition
+    # (north_star: 1e-3 fp32; asserted 1e-4 on outputs and input gradients, 1e-3 on parameter gradients).  GAT, the
+    # adaptive combine, residual sums and pooling are f32 torch glue in this mode (fusion_layers.py), the GEMMs, softmax
+    # and LayerNorm HIP.
+    m.precision = "fp32"
+    for p_ in m.parameters():
+        p_.grad.zero_()
+    x32 = [x.cuda().requires_grad_(True) for x in xs]
+    out32 = m(*x32, compute_contrastive_loss=True)
+    synth.probe_loss(out32).backward()
+    torch.cuda.synchronize()
+    m.precision = None
+    for k in HIER_KEYS:
+        want = ref[k].detach()
+        err = float((out32[k].detach().float().cpu() - want).abs().max()) / max(1.0, float(want.abs().max()))
+        assert err <= 1e-4, f"{name}: fp32 mode: {k} scaled abs err {err:.3e}"
+    for k, want in ref["contrastive_losses"].items():
+        assert abs(float(out32["contrastive_losses"][k]) - float(want)) <= 1e-4 * max(1.0, abs(float(want))), k
+    for i, (g, r) in enumerate(zip(x32, xr)):
+        assert l2_rel(g.grad, r.grad) <= 1e-4, f"{name}: fp32 mode: input grad {i} rel L2 {l2_rel(g.grad, r.grad):.3e}"
+    scale32 = max(float(v.grad.norm()) for v in P.values() if v.grad is not None)
+    w32 = ("", 0.0)
+    for pn, p_ in params.items():
+        want = P[pn].grad
+        if want is None or float(want.norm()) <= 1e-6 * scale32:
+            continue
+        e = l2_rel(p_.grad.detach().float().cpu(), want)
+        w32 = max(w32, (pn, e), key=lambda t: t[1])
+        assert e <= 1e-3, f"{name}: fp32 mode: param grad {pn} rel L2 {e:.3e}"
+    print(f"hier-seq {name}: fp32 mode worst parameter gradient vs the fp32 oracle {w32[1]:.3e} ({w32[0]})")
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -251,6 +302,125 @@ def test_training_step_matches_oracle_clip_adamw_onecycle():
         assert cos >= 0.8, f"step {step}: update direction cosine vs the all-oracle run {cos:.3f}"
         prev = got
     assert ts.opt.t == 2 and int(ts.opt.step_dev.item()) == 2
+
+
+def test_training_step_at_the_bench_size_matches_oracle_loss_and_gradient_norm():
+    """``FusionTrainStep`` at the size ``bench.py --workload train`` times (BASELINE configs[3]: hier-seq, B = 16,
+    T = 512/400/30, d = 768, H = 8, G = 768, L = 3 + classifier head): loss within 1e-2 and the global pre-clip gradient
+    norm within 5 % of the oracle's (reference recipe advanced_trainer.py:139-182), and the clipped update moves no
+    parameter by more than lr (1 + wd |p|) in the first Adam step."""
+    from mmfusion import arena as arena_mod
+    from mmfusion.train import FusionTrainStep, one_cycle_lr
+    S = synth.C2_SHAPES
+    from models import fusion_layers as fl
+    from models.multimodal_model import EmotionClassifier
+    cfg = _hier_cfg(S["d"], S["heads"], S["d"], 3)
+    torch.manual_seed(synth.WEIGHT_SEED)
+    fusion, head = fl.HierarchicalFusion(cfg), EmotionClassifier(cfg)
+
+    class FusionWithHead(fl._FusionBase):
+        def __init__(self):
+            super().__init__()
+            self.fusion_layer, self.classifier = fusion, head
+
+        def forward(self, t, a, v, compute_contrastive_loss=False):
+            return self.fusion_layer(t, a, v, compute_contrastive_loss=compute_contrastive_loss)
+    model = FusionWithHead()
+    xs = synth.make_features(S["B"], (S["T_text"], S["T_audio"], S["T_frames"]), S["d"])
+    labels = torch.randint(0, 7, (S["B"],), generator=torch.Generator().manual_seed(99))
+    names = [n for n, _ in model.named_parameters()]
+    P = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    torch.set_num_threads(16)
+    ref_loss = _oracle_train_loss(cfg, P, xs, labels)
+    ref_loss.backward()
+    ref_norm = math.sqrt(sum(float(P[n].grad.double().pow(2).sum()) for n in names if P[n].grad is not None))
+
+    model = model.cuda().train()
+    ar = arena_mod.ensure(model)
+    max_lr, total = 1e-4, 1000
+    ts = FusionTrainStep(model, model.classifier, ar, lr=max_lr, weight_decay=1e-5, max_grad_norm=1.0, total_steps=total)
+    before = ar.master.clone()
+    loss = ts(*[x.cuda() for x in xs], labels.cuda())
+    grads = ar.grads.clone()
+    torch.cuda.synchronize()
+    norm = float(grads.double().norm())
+    print(f"train step at the bench size: loss {float(loss):.5f} (oracle {float(ref_loss):.5f}), |g| {norm:.4f} (oracle {ref_norm:.4f})")
+    assert abs(float(loss) - float(ref_loss)) <= 1e-2 * max(1.0, abs(float(ref_loss)))
+    assert abs(norm - ref_norm) <= 0.05 * ref_norm
+    lr0 = one_cycle_lr(0, total, max_lr)
+    moved = (ar.master - before).abs()
+    # (2 f32 ulps of the parameter: `moved` is a difference of rounded f32 values)
+    assert float((moved - lr0 * (1.0 + 1e-5 * before.abs()) * 1.001 - 2.4e-7 * before.abs()).max()) <= 1e-9, \
+        "an update larger than the first Adam step allows"
+    assert float(moved.max()) > 0.5 * lr0, "the optimiser did not move the parameters"
+    assert int(ts.opt.step_dev.item()) == 1
+
+
+def test_optimizer_step_counter_survives_graph_replay_and_checkpoint(tmp_path):
+    """``FusedAdamW.advance()`` captured in a hipGraph moves the DEVICE step counter on every replay but the
+    host mirror only once; ``state_dict()`` must report the device's count, and a run resumed from the checkpoint must
+    continue exactly like the uninterrupted one (bias corrections, OneCycle position)."""
+    from mmfusion import arena as arena_mod
+    from mmfusion.train import FusedAdamW, load_checkpoint, save_checkpoint
+
+    def make():
+        torch.manual_seed(11)
+        lin = torch.nn.Sequential(torch.nn.Linear(64, 128), torch.nn.Linear(128, 64)).cuda()
+        ar = arena_mod.ensure(lin)
+        opt = FusedAdamW(ar, lr=1e-3, weight_decay=1e-5, max_grad_norm=1.0)
+        opt.set_schedule(1e-3, 50)
+        return lin, ar, opt
+
+    def fill(ar, k):
+        g = torch.Generator(device="cuda").manual_seed(100 + k)
+        ar.grads.copy_(torch.randn(ar.grads.shape, device="cuda", generator=g))
+
+    def captured(opt):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            opt.advance(); opt.launch()                       # one eager warm-up step (step 1)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            opt.advance(); opt.launch()
+        return g
+
+    # uninterrupted: the eager warm-up step (step 1; a capture executes nothing) + 6 replays = 7 steps
+    lin_a, ar_a, opt_a = make()
+    fill(ar_a, 0)
+    ga = captured(opt_a)
+    for k in range(6):
+        fill(ar_a, k + 1)
+        ga.replay()
+    torch.cuda.synchronize()
+    assert int(opt_a.step_dev.item()) == 7 and opt_a.t == 2            # the host mirror only saw the two Python calls
+    sd = opt_a.state_dict(lin_a.parameters())
+    assert float(sd["state"][0]["step"]) == 7.0, "state_dict reports the host mirror, not the device counter"
+
+    # interrupted after 3 replays (step 4): checkpoint, reload into a fresh optimiser, 3 more eager device-side steps
+    lin_b, ar_b, opt_b = make()
+    fill(ar_b, 0)
+    gb = captured(opt_b)
+    for k in range(3):
+        fill(ar_b, k + 1)
+        gb.replay()
+    path = str(tmp_path / "ck.pth")
+    save_checkpoint(path, lin_b, opt_b, epoch=1)
+    lin_c, ar_c, opt_c = make()
+    load_checkpoint(path, lin_c, opt_c)
+    assert opt_c.t == 4 and int(opt_c.step_dev.item()) == 4
+    for k in range(3, 6):
+        fill(ar_c, k + 1)
+        opt_c.advance(); opt_c.launch()
+    torch.cuda.synchronize()
+    assert int(opt_c.step_dev.item()) == 7
+    dev = float((ar_c.master - ar_a.master).abs().max())
+    assert dev <= 1e-7, f"resumed run deviates from the uninterrupted one by {dev:.3e}"
+    # and the host-side path after device-side steps: set_hparams must continue from the device's count
+    opt_a.set_hparams(lr=1e-3)
+    assert opt_a.t == 8 and int(opt_a.step_dev.item()) == 8
 
 
 # ------------------------------------------------------------------------------------------------------------

@@ -155,20 +155,9 @@ def test_mult_at_the_bench_configuration_matches_oracle():
     torch.set_num_threads(16)
     ref = ref_cpu.multimodal_transformer(P, "", *xr, S["heads"])
     synth.probe_loss(ref).backward()
-    # The tight check: the same arithmetic with bf16 storage (oracle rounds where the HIP path stores bf16).  Its loss
-    # leaves out `fused_features`: that output sits behind the ReLU of final_fusion over only B x d = 12,288 units, and
-    # ONE unit whose pre-activation lands on the other side of zero (|z| < ~1e-4 sigma; measured: a handful at this
-    # size) moves EVERY upstream gradient by ~1.3e-2 — the fp32 comparison above carries that path at its looser
-    # tolerance, the small fixtures carry it tightly (test_module_parity).  The three pooled projections reach every
-    # parameter below final_fusion: all nine attention cores, six cross blocks, pooling, out-projections.
-    def pooled_only(o):
-        return {k: v for k, v in o.items() if k != "fused_features"}
+    # The tight check further down: the same arithmetic with bf16 storage (the oracle rounds where the HIP path stores bf16).
     Pb = {k: v.detach().clone().requires_grad_(True) for k, v in P.items()}
     xb = [x.clone().requires_grad_(True) for x in xs]
-    with ref_cpu.bf16_storage():
-        ref_b = ref_cpu.multimodal_transformer(Pb, "", *xb, S["heads"])
-        synth.probe_loss(pooled_only(ref_b)).backward()
-
     m = m.cuda().eval()
 
     def run():
@@ -191,19 +180,35 @@ def test_mult_at_the_bench_configuration_matches_oracle():
         got = dict(m.named_parameters())[name].grad.float().cpu()
         tol = GP_L2_RELU if any(t in name for t in RELU_FED) else GP_L2
         assert l2_rel(got, P[name].grad) <= tol, f"param grad {name}: {l2_rel(got, P[name].grad):.3e}"
-    for k, want in ref_b.items():                        # forward against the bf16-storage oracle
+    # ---- against the bf16-storage oracle, flip-aware: the units of fused_features whose ReLU state
+    # differs between the two sides are counted (few) and left out of the probe loss on BOTH sides — fused_features feeds
+    # nothing else, so masking it in the loss switches those units off completely — and then EVERY gradient, final_fusion's
+    # included, must agree to 2e-2.  (Round 2 left fused_features out of this comparison altogether.)
+    with ref_cpu.bf16_storage(), torch.no_grad():
+        ref_b0 = ref_cpu.multimodal_transformer({k: v.detach() for k, v in P.items()}, "", *xs, S["heads"])
+    for k, want in ref_b0.items():                       # forward against the bf16-storage oracle
         assert l2_rel(out[k], want) <= OUT_BF16, f"{k} vs bf16-storage oracle rel L2 {l2_rel(out[k], want):.3e}"
+    agree = ((out["fused_features"].detach().float().cpu() > 0) == (ref_b0["fused_features"] > 0)).float()
+    nflip = int((1 - agree).sum())
+    print(f"bench config: {nflip} of {agree.numel()} fused_features units differ in ReLU state from the bf16-storage oracle")
+    assert nflip <= max(2, int(3e-3 * agree.numel())), f"{nflip} of {agree.numel()} top-level ReLU units flipped"      # measured 0.17 %
+
+    def masked(o, mask):
+        o = dict(o)
+        o["fused_features"] = o["fused_features"] * mask
+        return o
+    with ref_cpu.bf16_storage():
+        ref_b = ref_cpu.multimodal_transformer(Pb, "", *xb, S["heads"])
+        synth.probe_loss(masked(ref_b, agree)).backward()
     xg3 = [x.cuda().requires_grad_(True) for x in xs]
     for p in m.parameters():
         p.grad.zero_()
-    synth.probe_loss(pooled_only(m(*xg3))).backward()
+    synth.probe_loss(masked(m(*xg3), agree.cuda())).backward()
     torch.cuda.synchronize()
     worst = 0.0
     for g, rb in zip(xg3, xb):
         assert l2_rel(g.grad, rb.grad) <= GIN_L2_BF16, f"input grad vs bf16-storage oracle rel L2 {l2_rel(g.grad, rb.grad):.3e}"
-    for name, p in m.named_parameters():                 # EVERY parameter gradient below final_fusion
-        if name.startswith("final_fusion"):
-            continue
+    for name, p in m.named_parameters():                 # EVERY parameter gradient
         e = l2_rel(p.grad.float().cpu(), Pb[name].grad)
         worst = max(worst, e)
         assert e <= GP_L2_BF16, f"param grad {name} vs bf16-storage oracle: {e:.3e}"
