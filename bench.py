@@ -98,12 +98,14 @@ def build(workload, device, rank, dropout=0.0, input_grads=True):
     return cfg, model, xs
 
 
-def make_train_step(model, xs, arena, world, allreduce, rank):
+def make_train_step(model, xs, arena, world, allreduce, rank, shard_optimizer=False):
     """hierarchical-fusion TRAINING step (BASELINE configs[3]): zero grads, forward, CE(ls=0.1) + 0.1 *
     contrastive, backward | RCCL all-reduce | clip(1.0) + AdamW (fused, also refreshes the bf16 shadow)."""
     from mmfusion import dp
     from mmfusion.train import FusedAdamW, fusion_loss, one_cycle_lr
-    opt = FusedAdamW(arena, lr=1e-4, weight_decay=1e-5, max_grad_norm=1.0)
+    # --shard-optimizer (N > 1): ZeRO-1 step — reduce-scatter of the gradients, AdamW on this rank's 1/N of the arena,
+    # all-gather of the bf16 shadow — instead of all-reduce + replicated AdamW (mmfusion.train.FusedAdamW.launch_sharded)
+    opt = FusedAdamW(arena, lr=1e-4, weight_decay=1e-5, max_grad_norm=1.0, shard=shard_optimizer)
     g = torch.Generator().manual_seed(99 + rank)
     labels = torch.randint(0, 7, (xs[0].shape[0],), generator=g).to(xs[0].device)
 
@@ -125,9 +127,9 @@ def make_train_step(model, xs, arena, world, allreduce, rank):
         opt.launch()
 
     def exchange():
-        if world > 1:
+        if world > 1 and not opt.sharded:
             dp.allreduce_grads(arena, compress=None if allreduce == "fp32" else "bf16")
-    return fwd_bwd, before_replay, exchange, opt_launch
+    return fwd_bwd, before_replay, exchange, opt_launch, opt.sharded
 
 
 def make_step(workload, model, xs, arena):
@@ -350,6 +352,9 @@ def main():
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only to rehearse the "
                          "multi-rank code path on a box with fewer GPUs than ranks)")
+    ap.add_argument("--shard-optimizer", action="store_true",
+                    help="train workload, N > 1: ZeRO-1 optimiser step (reduce-scatter, AdamW on 1/N of the arena, all-gather "
+                         "of the bf16 shadow) instead of all-reduce + replicated AdamW")
     ap.add_argument("--allreduce", choices=["bf16", "fp32"], default="bf16",
                     help="wire dtype of the gradient all-reduce for N > 1 (compute and accumulation stay as is)")
     args = ap.parse_args()
@@ -459,6 +464,8 @@ def main():
         try:
             return capture_split(body)
         except Exception as e:                                   # noqa: BLE001 - any capture failure means: do not overlap
+            if os.environ.get("MMF_DP_STRICT") == "1":            # a scaling run must not silently measure the fallback
+                raise
             fallback["reason"] = f"{type(e).__name__}: {e}"[:300]
             if rank == 0:
                 print(f"bench: overlapped exchange disabled ({fallback['reason']})", file=sys.stderr, flush=True)
@@ -482,7 +489,10 @@ def main():
         overlap = want_overlap
         graph = graph2 = split = None
         if args.workload == "train":
-            fwd_bwd, before_replay, exchange, opt_launch = make_train_step(model, xs, arena, world, args.allreduce, rank)
+            fwd_bwd, before_replay, exchange, opt_launch, sharded = make_train_step(model, xs, arena, world, args.allreduce,
+                                                                                    rank, args.shard_optimizer)
+            if sharded:
+                overlap = False            # no gradient all-reduce to overlap: the sharded step reduce-scatters itself
 
             def eager_step():
                 fwd_bwd()
@@ -502,7 +512,8 @@ def main():
                     overlap = split is not None
                 if not overlap:
                     graph = capture(fwd_bwd)
-                graph2 = capture(opt_launch)
+                if not sharded:            # the sharded step holds collectives: it runs eagerly between the replays
+                    graph2 = capture(opt_launch)
 
             def run_step():
                 if overlap:
@@ -511,7 +522,10 @@ def main():
                 elif graph is not None:
                     graph.replay()
                     exchange()
-                    graph2.replay()
+                    if graph2 is not None:
+                        graph2.replay()
+                    else:
+                        opt_launch()
                 else:
                     eager_step()
             return run_step, profile_step, overlap
@@ -593,6 +607,7 @@ def main():
                    "weight_shadow": "re-cast every step" if args.recast_weights else "cached while the masters are unchanged",
                    "global_batch": B * world, "parallelism": f"dp{world}",
                    "grad_allreduce": (args.allreduce if world > 1 else None), "allreduce_overlaps_wgrad": bool(overlap),
+                   "sharded_optimizer": bool(args.shard_optimizer and world > 1),
                    "overlap_fallback": fallback["reason"], "graph_replay": bool(use_graph)},
         # algorithmic FLOPs of the GEMM / attention problems actually launched in one step / step time
         "step_gflop_launched": round(launched_flops / 1e9, 1),

@@ -27,6 +27,8 @@ import torch
 from . import lib
 
 ALIGN = 64
+SHARD_ALIGN = 64 * 16          # arena storage granularity: equal 64-aligned shards for up to 16 ranks
+SMALL_NUMEL = 1 << 16          # 2-D parameters below this size count as "small" (read as fp32 masters by the small kernels)
 # Side-stream (fork/join) execution of the late shadow cast and of the gradient zeroing.  OFF by default:
 # measured on MI355X (same box, graph replay) it is a wash for MulT (3.09 vs 3.08-3.09 ms: the streams
 # compete with the in-projection GEMM for HBM) and a loss for the hierarchical training step (6.30 vs
@@ -68,9 +70,16 @@ class ParamArena:
         # stable: attention in-projections first, then the other matrices, then the vectors (biases, LayerNorm):
         # the matrices' gradients are produced by the wgrad GEMMs, which can overwrite instead of accumulate
         # (zero_grad(lazy=True)), so what still needs a memset each step is the contiguous tail
-        named.sort(key=lambda np_: 2 if np_[1].dim() < 2 else (0 if _is_early(np_[0]) else 1))
+        # (round 3) "small" = everything that is not a big 2-D GEMM weight: vectors, (1, H, G) attention vectors, embeddings,
+        # the d -> 7 / 3 / 1 heads.  The small kernels read these as fp32 MASTERS (exact, no shadow); the big matrices are
+        # only ever read through the bf16 shadow.  Keeping the small ones together at the tail lets the sharded optimiser
+        # step refresh their masters on every rank with one tiny collective (FusedAdamW.launch_sharded).
+        def _small(q):
+            return q.dim() != 2 or q.numel() < SMALL_NUMEL
+        named.sort(key=lambda np_: 2 if _small(np_[1]) else (0 if _is_early(np_[0]) else 1))
         params: List[torch.nn.Parameter] = [p for _, p in named]
-        n_early = sum(1 for n, q in named if _is_early(n) and q.dim() >= 2)
+        n_early = sum(1 for n, q in named if _is_early(n) and not _small(q))
+        n_big = sum(1 for _, q in named if not _small(q))
         dev = params[0].device
         if dev.type != "cuda":
             raise RuntimeError("mmfusion: the fusion path runs on the GPU only; move the module to a "
@@ -85,11 +94,18 @@ class ParamArena:
             off += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
         self.numel = off
         self.early_numel = self.offsets[n_early] if n_early < len(params) else off
+        self.small_start = self.offsets[n_big] if n_big < len(params) else off      # first element of the small-parameter tail
         self._side: Optional[torch.cuda.Stream] = None      # fork/join stream for late cast + grad zeroing
         self._pending = False
-        self.master = torch.zeros(off, dtype=torch.float32, device=dev)
-        self.shadow = torch.zeros(off, dtype=torch.bfloat16, device=dev)
-        self.grads = torch.zeros(off, dtype=torch.float32, device=dev)
+        # The storage is padded to SHARD_ALIGN elements so that it divides into equal, 64-element-aligned shards for
+        # world sizes 2, 4, 8, 16: the sharded optimiser step under data parallelism (mmfusion.train.FusedAdamW(shard=True):
+        # in-place reduce-scatter of `grads_full`, all-gather of `shadow_full`) works on the *_full tensors; everything else
+        # sees the first `numel` elements.
+        self.capacity = (off + SHARD_ALIGN - 1) // SHARD_ALIGN * SHARD_ALIGN
+        self.master_full = torch.zeros(self.capacity, dtype=torch.float32, device=dev)
+        self.shadow_full = torch.zeros(self.capacity, dtype=torch.bfloat16, device=dev)
+        self.grads_full = torch.zeros(self.capacity, dtype=torch.float32, device=dev)
+        self.master, self.shadow, self.grads = self.master_full[:off], self.shadow_full[:off], self.grads_full[:off]
         with torch.no_grad():
             for p, o in zip(params, self.offsets):
                 n = p.numel()

@@ -158,6 +158,89 @@ def allreduce_grads_range_async(arena, start: int, end: int, group=None, bucket_
     return _RangePending(arena, items, world, compress)
 
 
+class BackwardExchange:
+    """The gradient exchange moved INTO backward (SURVEY.md 8e as specified: buckets in reverse-autograd order, each put
+    on the wire as soon as backward has produced it).  ``install()`` registers a round hook with the deferred wgrad
+    queue (``ops.set_wgrad_rounds``): every round's weight-gradient GEMMs are issued at once on the wgrad side stream and
+    the mean all-reduce of the gradient-arena runs they complete is started right behind them, while the main stream
+    goes on with the backward pass; ``finish()`` (after ``arena.finalize_grads()``) starts the exchange of everything no
+    round covered — biases, LayerNorm vectors, torch-produced gradients, regions that got no gradient — and waits for
+    all of it, so the arena holds the mean over ranks of every element, each reduced exactly once.
+
+    Eager steps only: nothing here is captured into a hipGraph (the collectives run on RCCL's own stream).  Unmeasured
+    on RCCL hardware; the logic is covered by tests/test_dp_rounds_cpu.py on two gloo ranks."""
+
+    def __init__(self, arena, rounds: int = 4, compress: Optional[str] = "bf16", group=None,
+                 bucket_bytes: int = DEFAULT_BUCKET_BYTES):
+        self.arena, self.rounds, self.compress, self.group, self.bucket_bytes = arena, rounds, compress, group, bucket_bytes
+        self._handles: List[_RangePending] = []
+        self._sent: List[tuple] = []                     # (start, end) element runs already on the wire this step
+        self.rounds_seen = 0                             # hook calls of the current step (tests, logging)
+
+    def install(self) -> "BackwardExchange":
+        from . import ops
+        ops.set_wgrad_rounds(self.rounds, self._on_round)
+        return self
+
+    def remove(self) -> None:
+        from . import ops
+        ops.set_wgrad_rounds(0, None)
+
+    # -- overridable: how a round's GEMMs are issued (the CPU logic test substitutes torch arithmetic) -----------------
+    def _issue(self, problems) -> None:
+        from . import ops
+        if self.arena.grads.is_cuda:
+            ops._issue_wgrad_side(problems, all_streams=True)      # on the wgrad stream, behind every producer stream
+        else:
+            ops.issue_wgrad(problems)
+
+    def _stream(self):
+        from . import ops
+        if self.arena.grads.is_cuda and ops._wgrad_stream is not None:
+            return torch.cuda.stream(ops._wgrad_stream)
+        import contextlib
+        return contextlib.nullcontext()
+
+    def _runs(self, problems) -> List[tuple]:
+        """coalesced (start, end) element runs of the weight-gradient regions of `problems` inside the arena"""
+        base = self.arena.grads.data_ptr()
+        spans = sorted(((q[2].data_ptr() - base) // 4, (q[2].data_ptr() - base) // 4 + q[2].numel()) for q in problems)
+        runs: List[list] = []
+        for s0, e0 in spans:
+            s0, e0 = s0 // 64 * 64, (e0 + 63) // 64 * 64            # parameters start on 64-element boundaries
+            if runs and s0 <= runs[-1][1]:
+                runs[-1][1] = max(runs[-1][1], e0)
+            else:
+                runs.append([s0, e0])
+        return [(a, min(b, self.arena.numel)) for a, b in runs]
+
+    def _on_round(self, problems, final: bool) -> None:
+        self.rounds_seen += 1
+        if problems:
+            self._issue(problems)
+        if final or not problems:
+            return                                       # the last round's regions go out with the rest in finish()
+        with self._stream():
+            for s0, e0 in self._runs(problems):
+                self._handles.append(allreduce_grads_range_async(self.arena, s0, e0, self.group, self.bucket_bytes, self.compress))
+                self._sent.append((s0, e0))
+
+    def finish(self) -> None:
+        """Call after backward AND ``arena.finalize_grads()``: exchange what no round sent, then wait for everything."""
+        if self.arena.grads.is_cuda:
+            from . import ops
+            if ops._wgrad_stream is not None:            # the final round's GEMMs ran on the wgrad stream
+                torch.cuda.current_stream().wait_stream(ops._wgrad_stream)
+        pos = 0
+        for s0, e0 in sorted(self._sent) + [(self.arena.numel, self.arena.numel)]:
+            if s0 > pos:
+                self._handles.append(allreduce_grads_range_async(self.arena, pos, s0, self.group, self.bucket_bytes, self.compress))
+            pos = max(pos, e0)
+        for h in self._handles:
+            h.finish()
+        self._handles, self._sent, self.rounds_seen = [], [], 0
+
+
 def broadcast_params(arena, src: int = 0, group=None) -> None:
     """Make the replicas identical (rank ``src``'s masters win), then refresh the bf16 shadow."""
     if dist.is_initialized() and dist.get_world_size(group) > 1:

@@ -418,12 +418,67 @@ def issue_wgrad(pend: List[tuple]) -> None:
         _issue_wgrad(pend)
 
 
+# Round flush (data-parallel exchange INSIDE backward, SURVEY 8e / VERDICT r2 item 5a): with a hook installed, the backward
+# hands its queued weight-gradient problems over in `n` rounds in reverse-autograd order — round i as soon as i/n of the
+# problems the PREVIOUS backward queued have been queued again — and whatever is left from the end-of-backward callback
+# (final=True).  The hook issues a round's GEMMs and starts the all-reduce of the gradient regions they complete
+# (mmfusion.dp.BackwardExchange), so the exchange of the early rounds runs beside the rest of backward.  A region with
+# several writers in one backward (a weight used twice) only completes with its last writer: such problems are held back
+# for the final round (the set is learned from the previous backward, like the count).  The first backward after
+# installing the hook has nothing to learn from and delivers everything in the final round.
+_ROUND_HOOK = None
+_ROUND_N = 0
+_round_issued = 0
+_multi_writer: set = set()
+_round_ptrs: List[int] = []          # gradient pointers handed over in this backward's earlier rounds
+_rounds_cut = 0                      # rounds handed over so far in this backward
+
+
+def set_wgrad_rounds(n: int, hook) -> None:
+    """hook(problems, final) or None to remove.  Needs the deferred queue (MMF_DEFER_WGRAD=1); excludes the manual flush."""
+    global _ROUND_HOOK, _ROUND_N, _round_issued, _expected_wgrad
+    if hook is not None and (not DEFER_WGRAD or _MANUAL_FLUSH or n < 1):
+        raise RuntimeError("wgrad rounds need the deferred wgrad queue, no manual flush, n >= 1")
+    _ROUND_HOOK, _ROUND_N, _round_issued = hook, int(n), 0
+    _expected_wgrad = 0
+
+
+def _maybe_cut_round() -> None:
+    """queue_wgrad: hand over a round when its share of the expected problems has been queued."""
+    global _pending_wgrad, _round_issued
+    if _ROUND_HOOK is None or not _expected_wgrad or _ROUND_N < 2:
+        return
+    global _rounds_cut
+    done = _round_issued + len(_pending_wgrad)
+    k = _rounds_cut + 1                                                # the round being filled, 1-based
+    if k >= _ROUND_N or done * _ROUND_N < k * _expected_wgrad:
+        return                                                         # (the last round is the end-of-backward callback's)
+    _rounds_cut = k
+    ready = [q for q in _pending_wgrad if q[2].data_ptr() not in _multi_writer]
+    if not ready:
+        return
+    _pending_wgrad = [q for q in _pending_wgrad if q[2].data_ptr() in _multi_writer]
+    _round_issued += len(ready)
+    _round_ptrs.extend(q[2].data_ptr() for q in ready)
+    _ROUND_HOOK(ready, False)
+
+
 def _flush_wgrad() -> None:
-    global _pending_wgrad, _callback_queued, _pending_tiles, _expected_wgrad, _early_issued
+    global _pending_wgrad, _callback_queued, _pending_tiles, _expected_wgrad, _early_issued, _round_issued, _multi_writer
     pend, _pending_wgrad = _pending_wgrad, []
     _callback_queued, _pending_tiles = False, 0
     early, _early_issued = _early_issued, 0
-    _expected_wgrad = early + len(pend)                  # what the next backward is expected to queue
+    global _rounds_cut
+    rounds_done, _round_issued, _rounds_cut = _round_issued, 0, 0
+    _expected_wgrad = early + rounds_done + len(pend)    # what the next backward is expected to queue
+    if _ROUND_HOOK is not None:
+        seen: dict = {}
+        for ptr in _round_ptrs + [q[2].data_ptr() for q in pend]:
+            seen[ptr] = seen.get(ptr, 0) + 1
+        _multi_writer = {ptr for ptr, c in seen.items() if c > 1}
+        _round_ptrs.clear()
+        _ROUND_HOOK(pend, True)
+        return
     if _branch_streams:                                  # operands queued by backward nodes that ran on a branch stream
         cur = torch.cuda.current_stream()
         join_branch_streams()
@@ -465,8 +520,9 @@ def queue_wgrad(dy: torch.Tensor, x: torch.Tensor, wgrad: torch.Tensor, bgrad: O
         torch.autograd.Variable._execution_engine.queue_callback(_flush_wgrad)
         _callback_queued = True
     _pending_wgrad.append((dy, x, wgrad, bgrad, None, overwrite))
+    _maybe_cut_round()
     global _early_issued
-    if (_WGRAD_EARLY and not _WGRAD_SIDE and not _MANUAL_FLUSH and _expected_wgrad and not _early_issued
+    if (_WGRAD_EARLY and not _WGRAD_SIDE and not _MANUAL_FLUSH and _ROUND_HOOK is None and _expected_wgrad and not _early_issued
             and len(_pending_wgrad) == _expected_wgrad):
         pend, _pending_wgrad = _pending_wgrad, []
         _early_issued = len(pend)

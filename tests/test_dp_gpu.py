@@ -1,0 +1,123 @@
+"""GPU, two gloo ranks SHARING the one GPU of the box (the N > 1 code paths with the real kernels; RCCL itself cannot run
+with two ranks on one device, so the wire is gloo — this checks schedules and arithmetic, not RCCL timing):
+
+  * bench.py's overlapped exchange (three hipGraphs, range all-reduces between the replays) leaves the same gradient arena
+    as the one-shot exchange (the MMF_BENCH_CHECKSUM comparison as a committed test), with
+    MMF_DP_STRICT=1 so that a failed split capture fails the test instead of silently measuring the fallback (5d);
+  * ``FusionTrainStep`` with the exchange inside backward (``exchange="backward"``) and with the ZeRO-1 sharded optimiser
+    (``shard_optimizer=True``) ends two training steps with the same parameters as the plain step (all-reduce after
+    backward, replicated AdamW), on both ranks (5a, 5b)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(overlap: str, port: int):
+    env = dict(os.environ, MMF_BENCH_CHECKSUM="1", MMF_DP_OVERLAP=overlap, MMF_DP_STRICT="1", MASTER_ADDR="127.0.0.1",
+               MMFUSION_CONFIG_MKDIRS="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", "2", "--backend", "gloo", "--allreduce", "fp32",
+           "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--profile-steps", "1"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    return json.loads(line)
+
+
+def test_overlapped_exchange_leaves_the_same_gradients_as_the_one_shot_exchange():
+    base = 36500 + (os.getpid() % 1500)
+    a = _bench("1", base)
+    b = _bench("0", base + 1)
+    assert a["config"]["allreduce_overlaps_wgrad"] is True and a["config"]["overlap_fallback"] is None
+    assert b["config"]["allreduce_overlaps_wgrad"] is False
+    (abs_a, sum_a), (abs_b, sum_b) = a["grad_checksum"], b["grad_checksum"]
+    assert abs(abs_a - abs_b) <= 1e-9 * abs_b and abs(sum_a - sum_b) <= 1e-9 * abs_b, (a["grad_checksum"], b["grad_checksum"])
+
+
+def _train_worker(rank, world, port, q):
+    for p in (REPO, os.path.join(REPO, "simple-multimodal_amd"), os.path.join(REPO, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ["MMFUSION_CONFIG_MKDIRS"] = "0"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    import config as cfgmod
+    from mmfusion import arena as arena_mod, synth
+    from mmfusion.train import FusionTrainStep
+    from models import fusion_layers as fl
+    from models.multimodal_model import EmotionClassifier
+
+    def run(mode):
+        cfg = cfgmod.ModelConfig()
+        cfg.fusion_hidden_size, cfg.fusion_num_heads, cfg.graph_hidden_size, cfg.graph_num_layers = 128, 2, 128, 2
+        cfg.fusion_dropout = cfg.graph_dropout = 0.0
+        torch.manual_seed(3)
+        fusion, head = fl.HierarchicalFusion(cfg), EmotionClassifier(cfg)
+
+        class FusionWithHead(fl._FusionBase):
+            def __init__(self):
+                super().__init__()
+                self.fusion_layer, self.classifier = fusion, head
+
+            def forward(self, t, a, v, compute_contrastive_loss=False):
+                return self.fusion_layer(t, a, v, compute_contrastive_loss=compute_contrastive_loss)
+        model = FusionWithHead().cuda().train()
+        ar = arena_mod.ensure(model)
+        kw = {"after": {}, "backward": {"exchange": "backward", "exchange_rounds": 4}, "sharded": {"shard_optimizer": True}}[mode]
+        ts = FusionTrainStep(model, model.classifier, ar, lr=1e-3, weight_decay=1e-5, max_grad_norm=1.0, total_steps=20,
+                             allreduce="fp32", **kw)
+        xs = [x.cuda() for x in synth.make_features(8, (12, 10, 5), 128, seed=21 + rank)]      # a different batch per rank
+        labels = torch.randint(0, 7, (8,), generator=torch.Generator().manual_seed(5 + rank)).cuda()
+        gmin = None
+        for _ in range(2):                           # (a third step already amplifies last-bit differences of the parameters
+            ts(*xs, labels)                          #  through flipped ReLU units: two PLAIN runs differ by ~lr there)
+            if mode == "after":                      # the averaged gradient of this step is still in the arena
+                g = ar.grads.abs() / ar.grads.abs().max()
+                gmin = g if gmin is None else torch.minimum(gmin, g)
+        ts.opt.gather_masters()
+        torch.cuda.synchronize()
+        if ts._bx is not None:
+            ts._bx.remove()
+        return ar.master.detach().cpu().clone(), (None if gmin is None else gmin.cpu())
+    out = {m: run(m) for m in ("after", "backward", "sharded")}
+    q.put((rank, {m: v[0].numpy() for m, v in out.items()}, out["after"][1].numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_exchange_in_backward_and_sharded_optimizer_match_the_plain_step():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 38500 + (os.getpid() % 1500)
+    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=400) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    import numpy as np
+    ref, gmin = res[0][1]["after"], res[0][2]
+    assert np.abs(ref).max() > 0
+    # Adam's first steps move a parameter by ~lr * g / (|g| + eps) whatever the gradient's size: where the gradient is
+    # rounding noise around an exact zero (key biases of a softmax, dead units) its SIGN — and with it a whole +-lr step —
+    # depends on the summation order, in torch as much as here.  So: parameters whose gradient was above 1e-5 of the
+    # arena's largest in both steps must agree to f32 rounding; the rest can differ by the two steps' lr at most.
+    solid = gmin > 1e-5
+    assert solid.mean() > 0.5
+    for rank, out, _ in res:
+        for mode, v in out.items():
+            d = np.abs(v - ref)
+            assert float(d[solid].max()) <= 2e-5, f"rank {rank}, {mode}: parameters deviate from rank 0's plain run by {float(d[solid].max()):.3e}"
+            assert float(d.max()) <= 2 * 1e-3 * 1.01 + 1e-6, f"rank {rank}, {mode}: {float(d.max()):.3e}"
