@@ -12,10 +12,13 @@ constexpr int MAX_CH = 4;              // 4 chunks x 64 lanes x 8 elements = 204
 
 constexpr int BWD_BLOCK_BUDGET = 2048;  // upper bound of workgroups of a grouped backward launch (workspace rows)
 // workgroups actually used (MMF_LN_BWD_BLOCKS, default below): enough rows in flight per CU to cover the HBM latency
-static int bwd_blocks() {
-  static const int v = [] { const char* e = getenv("MMF_LN_BWD_BLOCKS"); int b = e ? atoi(e) : 2048;
-                            return b < 64 ? 64 : (b > BWD_BLOCK_BUDGET ? BWD_BLOCK_BUDGET : b); }();
-  return v;
+static int bwd_blocks(bool lane_form) {
+  // the lane form keeps its next row in flight, so two workgroups per CU already cover the HBM latency, and fewer partial
+  // rows are left for the finalize pass (round 3, same box: 2048 / 1024 / 512 workgroups 23.5 / 20.5 / 19.9 us per
+  // three-problem launch, finalize included; the chunk form 25.1 / 24.1 / 23.8)
+  static const int v = [] { const char* e = getenv("MMF_LN_BWD_BLOCKS"); return e ? atoi(e) : 0; }();
+  const int b = v > 0 ? v : (lane_form ? 512 : 2048);
+  return b < 64 ? 64 : (b > BWD_BLOCK_BUDGET ? BWD_BLOCK_BUDGET : b);
 }
 
 struct LnArgs {
@@ -190,6 +193,134 @@ void ln_bwd_kernel(const LnArgs a) {
   }
 }
 
+// Round 3: the same backward for d = 512 NV + 256 H8 (768 = 512 + 256, 512, 1024, 256 ...) with every lane busy and the
+// next row in flight.  ln_bwd_kernel above gives lane l the 16-byte chunks l, l + 64, ...: at d = 768 the second chunk only
+// exists for lanes 0-31 (a quarter of the loads and of the arithmetic runs half empty), gamma is re-read from L2 for every
+// row (as many bytes as x and dy together), and a wave asks for a row only after it has reduced and stored the one before
+// (profiles/r03_layernorm.txt: 2.8 TB/s of algorithmic bytes for the three-problem launches, finalize included).  Here lane l
+// owns columns [8 l, 8 l + 8) of each 512-column block (16-byte loads) and [512 NV + 4 l, + 4) of the last 256 (8-byte
+// loads), gamma stays in registers, and the loads of the wave's next row are issued before the reductions of the current.
+template <int NV, int H8>
+__global__ __launch_bounds__(256)
+void ln_bwd_lane_kernel(const LnArgs a) {
+  constexpr int EP = 8 * NV + 4 * H8;                 // elements per lane
+  __shared__ float red[2][3][64 * EP];                // [dgamma|dbeta][waves 1..3][lane-major element]
+  int pi = 0;
+  while (pi + 1 < a.nprob && (int)blockIdx.x >= a.blk_start[pi + 1]) ++pi;
+  const mmf_ln_problem& P = a.p[pi];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nblk = a.blk_start[pi + 1] - a.blk_start[pi];
+  constexpr int d = 512 * NV + 256 * H8;
+  const float inv_d = 1.f / (float)d;
+  float gam[EP], dg[EP], db[EP];
+#pragma unroll
+  for (int c = 0; c < NV; ++c) {
+    const f32x4_t g0 = *reinterpret_cast<const f32x4_t*>(P.gamma + 512 * c + 8 * lane);
+    const f32x4_t g1 = *reinterpret_cast<const f32x4_t*>(P.gamma + 512 * c + 8 * lane + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { gam[8 * c + e] = g0[e]; gam[8 * c + 4 + e] = g1[e]; }
+  }
+  if (H8) {
+    const f32x4_t g0 = *reinterpret_cast<const f32x4_t*>(P.gamma + 512 * NV + 4 * lane);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) gam[8 * NV + e] = g0[e];
+  }
+#pragma unroll
+  for (int e = 0; e < EP; ++e) { dg[e] = 0.f; db[e] = 0.f; }
+
+  struct Row { u32x4_t x[NV > 0 ? NV : 1], y[NV > 0 ? NV : 1]; u32x2_t x8, y8; float mean, rstd; };
+  auto fetch = [&](int row, Row& r) {
+    const unsigned short* x = static_cast<const unsigned short*>(P.x) + (size_t)row * d;
+    const unsigned short* dy = static_cast<const unsigned short*>(P.dy) + (size_t)row * d;
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+      r.x[c] = *reinterpret_cast<const u32x4_t*>(x + 512 * c + 8 * lane);
+      r.y[c] = *reinterpret_cast<const u32x4_t*>(dy + 512 * c + 8 * lane);
+    }
+    if (H8) {
+      r.x8 = *reinterpret_cast<const u32x2_t*>(x + 512 * NV + 4 * lane);
+      r.y8 = *reinterpret_cast<const u32x2_t*>(dy + 512 * NV + 4 * lane);
+    }
+    r.mean = P.mean[row];
+    r.rstd = P.rstd[row];
+  };
+  const int step = nblk * ROWS_PER_BLOCK;
+  int row = ((int)blockIdx.x - a.blk_start[pi]) * ROWS_PER_BLOCK + wave;
+  Row cur, nxt;
+  if (row < P.rows) fetch(row, cur);
+  for (; row < P.rows; row += step) {
+    const bool more = row + step < P.rows;
+    if (more) fetch(row + step, nxt);                  // in flight under this row's reductions and store
+    float xv[EP], dv[EP];
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+      float t[8];
+      unpack8(cur.x[c], t);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) xv[8 * c + e] = t[e];
+      unpack8(cur.y[c], t);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dv[8 * c + e] = t[e];
+    }
+    if (H8) {
+      xv[8 * NV + 0] = bf16lo(cur.x8[0]); xv[8 * NV + 1] = bf16hi(cur.x8[0]); xv[8 * NV + 2] = bf16lo(cur.x8[1]); xv[8 * NV + 3] = bf16hi(cur.x8[1]);
+      dv[8 * NV + 0] = bf16lo(cur.y8[0]); dv[8 * NV + 1] = bf16hi(cur.y8[0]); dv[8 * NV + 2] = bf16lo(cur.y8[1]); dv[8 * NV + 3] = bf16hi(cur.y8[1]);
+    }
+    const float mean = cur.mean, rstd = cur.rstd;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < EP; ++e) {
+      xv[e] = (xv[e] - mean) * rstd;                   // x hat
+      const float g = dv[e] * gam[e];
+      s1 += g;
+      s2 += g * xv[e];
+      dg[e] += dv[e] * xv[e];
+      db[e] += dv[e];
+      dv[e] = g;
+    }
+    const float c1 = wave_sum(s1) * inv_d, c2 = wave_sum(s2) * inv_d;
+    unsigned short* dx = static_cast<unsigned short*>(P.dx) + (size_t)row * d;
+    float o[EP];
+#pragma unroll
+    for (int e = 0; e < EP; ++e) o[e] = rstd * (dv[e] - c1 - xv[e] * c2);
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+      const u32x4_t w = {pack_bf16x2(o[8 * c], o[8 * c + 1]), pack_bf16x2(o[8 * c + 2], o[8 * c + 3]),
+                         pack_bf16x2(o[8 * c + 4], o[8 * c + 5]), pack_bf16x2(o[8 * c + 6], o[8 * c + 7])};
+      *reinterpret_cast<u32x4_t*>(dx + 512 * c + 8 * lane) = w;
+    }
+    if (H8) {
+      const u32x2_t w = {pack_bf16x2(o[8 * NV], o[8 * NV + 1]), pack_bf16x2(o[8 * NV + 2], o[8 * NV + 3])};
+      *reinterpret_cast<u32x2_t*>(dx + 512 * NV + 4 * lane) = w;
+    }
+    if (more) cur = nxt;
+  }
+  // combine the 4 waves' column sums; this workgroup's partials -> its workspace row (column order)
+  if (wave > 0) {
+#pragma unroll
+    for (int e = 0; e < EP; ++e) { red[0][wave - 1][e * 64 + lane] = dg[e]; red[1][wave - 1][e * 64 + lane] = db[e]; }
+  }
+  __syncthreads();
+  if (wave == 0) {
+    float* wsg = a.ws + (size_t)blockIdx.x * 2 * d;
+#pragma unroll
+    for (int e = 0; e < EP; ++e)
+#pragma unroll
+      for (int w = 0; w < 3; ++w) { dg[e] += red[0][w][e * 64 + lane]; db[e] += red[1][w][e * 64 + lane]; }
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+      *reinterpret_cast<f32x4_t*>(wsg + 512 * c + 8 * lane) = f32x4_t{dg[8 * c], dg[8 * c + 1], dg[8 * c + 2], dg[8 * c + 3]};
+      *reinterpret_cast<f32x4_t*>(wsg + 512 * c + 8 * lane + 4) = f32x4_t{dg[8 * c + 4], dg[8 * c + 5], dg[8 * c + 6], dg[8 * c + 7]};
+      *reinterpret_cast<f32x4_t*>(wsg + d + 512 * c + 8 * lane) = f32x4_t{db[8 * c], db[8 * c + 1], db[8 * c + 2], db[8 * c + 3]};
+      *reinterpret_cast<f32x4_t*>(wsg + d + 512 * c + 8 * lane + 4) = f32x4_t{db[8 * c + 4], db[8 * c + 5], db[8 * c + 6], db[8 * c + 7]};
+    }
+    if (H8) {
+      *reinterpret_cast<f32x4_t*>(wsg + 512 * NV + 4 * lane) = f32x4_t{dg[8 * NV], dg[8 * NV + 1], dg[8 * NV + 2], dg[8 * NV + 3]};
+      *reinterpret_cast<f32x4_t*>(wsg + d + 512 * NV + 4 * lane) = f32x4_t{db[8 * NV], db[8 * NV + 1], db[8 * NV + 2], db[8 * NV + 3]};
+    }
+  }
+}
+
 // second phase: dgamma[j] += sum over the problem's workgroups of their partials.  thread = column,
 // blockIdx.z = one of FIN_SLICES slices of the workgroup range; each slice ends in one f32 atomic per
 // column (FIN_SLICES adders per address).
@@ -285,7 +416,9 @@ extern "C" int mmf_layernorm_bwd_grouped(const mmf_ln_problem* problems, int num
   // Workgroups are shared out over the problems in proportion to their rows (~2 per CU in total);
   // each leaves one row of column partials in the workspace (same-row float atomics would run ~14x
   // below the streaming rate: MI355X_MICROARCH.md, Global float atomics), summed by the finalize pass.
-  const int budget = bwd_blocks();
+  static const int lane_form = [] { const char* e = getenv("MMF_LN_BWD_LANE"); return e ? atoi(e) : 1; }();
+  const bool use_lane = lane_form && (d == 768 || d == 512 || d == 256 || d == 1024);
+  const int budget = bwd_blocks(use_lane);
   for (int i = 0; i < num_problems; ++i) {
     const int rows = problems[i].rows;
     int nb = (int)(((long long)rows * budget + total_rows - 1) / total_rows);
@@ -298,6 +431,16 @@ extern "C" int mmf_layernorm_bwd_grouped(const mmf_ln_problem* problems, int num
   a.blk_start[num_problems] = total;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int nch = (d + 511) / 512;
+  if (use_lane) {
+    if (d == 768)       hipLaunchKernelGGL((ln_bwd_lane_kernel<1, 1>), dim3(total), dim3(256), 0, s, a);
+    else if (d == 512)  hipLaunchKernelGGL((ln_bwd_lane_kernel<1, 0>), dim3(total), dim3(256), 0, s, a);
+    else if (d == 256)  hipLaunchKernelGGL((ln_bwd_lane_kernel<0, 1>), dim3(total), dim3(256), 0, s, a);
+    else                hipLaunchKernelGGL((ln_bwd_lane_kernel<2, 0>), dim3(total), dim3(256), 0, s, a);
+    MMF_CHECK_LAUNCH("mmf_layernorm_bwd_grouped(lane)");
+    hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((d + 255) / 256, num_problems, FIN_SLICES), dim3(256), 0, s, a);
+    MMF_CHECK_LAUNCH("mmf_layernorm_bwd_grouped(finalize)");
+    return MMF_OK;
+  }
   switch (nch) {
     case 1: hipLaunchKernelGGL(ln_bwd_kernel<1>, dim3(total), dim3(256), 0, s, a); break;
     case 2: hipLaunchKernelGGL(ln_bwd_kernel<2>, dim3(total), dim3(256), 0, s, a); break;
