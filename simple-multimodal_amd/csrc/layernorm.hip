@@ -96,6 +96,85 @@ void ln_fwd_kernel(const LnArgs a) {
   if (lane == 0) { P.mean[row] = mean; P.rstd[row] = rstd; }
 }
 
+// Round 3: the forward in the lane form of ln_bwd_lane_kernel below (lane l owns columns [8 l, +8) of every 512-column block and
+// [512 NV + 4 l, +4) of the last 256; gamma / beta in registers instead of 6 KB of L2 reads per row; a workgroup's waves walk
+// strided rows with the next row's load in flight).
+template <int NV, int H8>
+__global__ __launch_bounds__(256)
+void ln_fwd_lane_kernel(const LnArgs a) {
+  constexpr int EP = 8 * NV + 4 * H8, d = 512 * NV + 256 * H8;
+  int pi = 0;
+  while (pi + 1 < a.nprob && (int)blockIdx.x >= a.blk_start[pi + 1]) ++pi;
+  const mmf_ln_problem& P = a.p[pi];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nblk = a.blk_start[pi + 1] - a.blk_start[pi];
+  const float inv_d = 1.f / (float)d;
+  float gam[EP], bet[EP];
+#pragma unroll
+  for (int c = 0; c < NV; ++c)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const f32x4_t g = *reinterpret_cast<const f32x4_t*>(P.gamma + 512 * c + 8 * lane + 4 * h);
+      const f32x4_t b = *reinterpret_cast<const f32x4_t*>(P.beta + 512 * c + 8 * lane + 4 * h);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { gam[8 * c + 4 * h + e] = g[e]; bet[8 * c + 4 * h + e] = b[e]; }
+    }
+  if (H8) {
+    const f32x4_t g = *reinterpret_cast<const f32x4_t*>(P.gamma + 512 * NV + 4 * lane);
+    const f32x4_t b = *reinterpret_cast<const f32x4_t*>(P.beta + 512 * NV + 4 * lane);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { gam[8 * NV + e] = g[e]; bet[8 * NV + e] = b[e]; }
+  }
+  struct Row { u32x4_t x[NV > 0 ? NV : 1]; u32x2_t x8; };
+  auto fetch = [&](int row, Row& r) {
+    const unsigned short* x = static_cast<const unsigned short*>(P.x) + (size_t)row * d;
+#pragma unroll
+    for (int c = 0; c < NV; ++c) r.x[c] = *reinterpret_cast<const u32x4_t*>(x + 512 * c + 8 * lane);
+    if (H8) r.x8 = *reinterpret_cast<const u32x2_t*>(x + 512 * NV + 4 * lane);
+  };
+  const int step = nblk * ROWS_PER_BLOCK;
+  int row = ((int)blockIdx.x - a.blk_start[pi]) * ROWS_PER_BLOCK + wave;
+  Row cur, nxt;
+  if (row < P.rows) fetch(row, cur);
+  for (; row < P.rows; row += step) {
+    const bool more = row + step < P.rows;
+    if (more) fetch(row + step, nxt);
+    float v[EP];
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+      float t[8];
+      unpack8(cur.x[c], t);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[8 * c + e] = t[e];
+    }
+    if (H8) { v[8 * NV] = bf16lo(cur.x8[0]); v[8 * NV + 1] = bf16hi(cur.x8[0]); v[8 * NV + 2] = bf16lo(cur.x8[1]); v[8 * NV + 3] = bf16hi(cur.x8[1]); }
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < EP; ++e) s += v[e];
+    const float mean = wave_sum(s) * inv_d;
+    float q = 0.f;
+#pragma unroll
+    for (int e = 0; e < EP; ++e) { v[e] -= mean; q += v[e] * v[e]; }
+    const float rstd = rsqrtf(wave_sum(q) * inv_d + a.eps);
+    unsigned short* y = static_cast<unsigned short*>(P.y) + (size_t)row * d;
+    float o[EP];
+#pragma unroll
+    for (int e = 0; e < EP; ++e) o[e] = v[e] * rstd * gam[e] + bet[e];
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+      const u32x4_t w = {pack_bf16x2(o[8 * c], o[8 * c + 1]), pack_bf16x2(o[8 * c + 2], o[8 * c + 3]),
+                         pack_bf16x2(o[8 * c + 4], o[8 * c + 5]), pack_bf16x2(o[8 * c + 6], o[8 * c + 7])};
+      *reinterpret_cast<u32x4_t*>(y + 512 * c + 8 * lane) = w;
+    }
+    if (H8) {
+      const u32x2_t w = {pack_bf16x2(o[8 * NV], o[8 * NV + 1]), pack_bf16x2(o[8 * NV + 2], o[8 * NV + 3])};
+      *reinterpret_cast<u32x2_t*>(y + 512 * NV + 4 * lane) = w;
+    }
+    if (lane == 0) { P.mean[row] = mean; P.rstd[row] = rstd; }
+    if (more) cur = nxt;
+  }
+}
+
 // Backward: a block owns a strided set of rows of ONE problem; each wave walks its rows, keeps the
 // dgamma/dbeta partial sums of its columns in registers, the 4 waves combine through LDS and the
 // block issues one f32 atomic per column (Guideline 12: reduce on chip, then one atomic per block).
@@ -380,6 +459,31 @@ extern "C" int mmf_layernorm_fwd_grouped(const mmf_ln_problem* problems, int num
   }
   a.blk_start[num_problems] = total;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  static const int fwd_lane = [] { const char* e = getenv("MMF_LN_FWD_LANE"); return e ? atoi(e) : 1; }();
+  static const int fwd_blocks_env = [] { const char* e = getenv("MMF_LN_FWD_BLOCKS"); return e ? atoi(e) : 0; }();
+  long long total_rows = 0;
+  for (int i = 0; i < num_problems; ++i) total_rows += problems[i].rows;
+  // (round 3, same box, chunk form / lane form: three problems of 15,072 rows 13.0 / 9.6 us with 1024 workgroups; all six,
+  // 30,144 rows, 20.7 / 16.4 us with 2048 — profiles/r03_layernorm.txt)
+  const int fwd_blocks = fwd_blocks_env > 0 ? fwd_blocks_env : (total_rows > 20000 ? 2048 : 1024);
+  if (fwd_lane && (d == 768 || d == 512 || d == 256 || d == 1024) && total > fwd_blocks) {
+    // lane form: a bounded number of workgroups shared out over the problems in proportion to their rows
+    int t2 = 0;
+    for (int i = 0; i < num_problems; ++i) {
+      const int rows = problems[i].rows, full = (rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+      int nb = (int)(((long long)rows * fwd_blocks + total_rows - 1) / total_rows);
+      nb = nb > full ? full : (nb < 1 ? 1 : nb);
+      a.blk_start[i] = t2;
+      t2 += nb;
+    }
+    a.blk_start[num_problems] = t2;
+    if (d == 768)       hipLaunchKernelGGL((ln_fwd_lane_kernel<1, 1>), dim3(t2), dim3(256), 0, s, a);
+    else if (d == 512)  hipLaunchKernelGGL((ln_fwd_lane_kernel<1, 0>), dim3(t2), dim3(256), 0, s, a);
+    else if (d == 256)  hipLaunchKernelGGL((ln_fwd_lane_kernel<0, 1>), dim3(t2), dim3(256), 0, s, a);
+    else                hipLaunchKernelGGL((ln_fwd_lane_kernel<2, 0>), dim3(t2), dim3(256), 0, s, a);
+    MMF_CHECK_LAUNCH("mmf_layernorm_fwd_grouped(lane)");
+    return MMF_OK;
+  }
   const int nch = (d + 511) / 512;
   switch (nch) {
     case 1: hipLaunchKernelGGL(ln_fwd_kernel<1>, dim3(total), dim3(256), 0, s, a); break;
