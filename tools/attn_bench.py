@@ -3,7 +3,7 @@
 
 Calls the C ABI directly (no autograd, no allocation in the timed region); each measurement is one hipGraph
 holding INNER back-to-back launches, replayed REPS times, so launch gaps do not enter the number.
-    python tools/attn_bench.py [fwd|bwd|both]       MMF_ATTN_IMPLS=1,2 selects the generations to compare
+    python tools/attn_bench.py [fwd|bwd|both]       MMF_ATTN_IMPLS lists the implementations timed (2 = attention2.hip, the only one since round 3)
 """
 import ctypes as C
 import os
@@ -78,7 +78,7 @@ def run(pairs, bwd):
 cross = [("t", "a"), ("t", "v"), ("a", "t"), ("a", "v"), ("v", "t"), ("v", "a")]
 selfp = [("t", "t"), ("a", "a"), ("v", "v")]
 what = sys.argv[1] if len(sys.argv) > 1 else "fwd"
-impls = [int(x) for x in os.environ.get("MMF_ATTN_IMPLS", "1,2,3").split(",")]
+impls = [int(x) for x in os.environ.get("MMF_ATTN_IMPLS", "2").split(",")]
 cases = [("cross x6", cross), ("self x3", selfp), ("t<-a only", [("t", "a")]), ("a<-t only", [("a", "t")]),
          ("t<-t only", [("t", "t")]), ("v<-t only", [("v", "t")]), ("t<-v only", [("t", "v")]),
          ("big2 t<-a,a<-t", [("t", "a"), ("a", "t")]), ("narrow4 x30", [("t", "v"), ("a", "v"), ("v", "t"), ("v", "a")]),

@@ -1,9 +1,9 @@
-# Round profile collection on the GPU box:  TAG=r02 bash tools/prof_all.sh   (then: python tools/collect_profiles.py r02 "note")
+# Round profile collection on the GPU box:  TAG=r03 bash tools/prof_all.sh   (then: python tools/collect_profiles.py r03 "note")
 set -x
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cd $R
-TAG=${TAG:-r02}
+TAG=${TAG:-r03}
 O=gpurun_out/$TAG
 mkdir -p $O
 timeout -k 10 120 python3 __graft_entry__.py smoke > $O/smoke.log 2>&1 || echo SMOKE_FAILED
@@ -24,8 +24,8 @@ timeout -k 10 200 python3 tools/step_launches.py mult > $O/step_launches.log 2>&
 unset MMF_BENCH_NO_FROZEN
 python3 bench.py > $O/bench_plain.log 2>&1
 python3 bench.py --dropout 0.1 --no-cpu-baseline > $O/bench_dropout.log 2>&1
-python3 bench.py --workload hier --no-cpu-baseline > $O/bench_hier.log 2>&1
-python3 bench.py --workload train --no-cpu-baseline > $O/bench_train.log 2>&1
+python3 bench.py --workload hier --steps 100 --warmup 20 --no-cpu-baseline > $O/bench_hier.log 2>&1
+python3 bench.py --workload train --steps 100 --warmup 20 --no-cpu-baseline > $O/bench_train.log 2>&1
 ORACLE_STORAGE=bf16 TOPK=4 python3 tools/parity_report.py > $O/parity_bf16.txt 2>&1
 TOPK=4 python3 tools/parity_report.py > $O/parity_fp32.txt 2>&1
 # keep what travels back small: the raw traces of the three --stats runs are summarised above
