@@ -104,11 +104,11 @@ typedef struct mmf_gemm_extra {
 int mmf_gemm_grouped_ex(const mmf_gemm_problem* problems, int num_problems, int layout, int epilogue,
                         int out_f32, const mmf_gemm_extra* extra, void* stream);
 
-/* Tuning hook: which kernel generation mmf_gemm_grouped dispatches to (0 automatic [default], 1 register-staged 128x128,
- * 2 LDS-DMA ring 256x128, 3 persistent LDS-DMA ring, 4 LDS-DMA ring 256x256, 5 NT-only 256x128 with a 32-deep k-step and
- * two workgroups per CU [other layouts: 2]).  Automatic = 4 where the 256x256 tiling fills its CU rounds, else 5 for
- * NT launches with K <= 1024, else 2.  Results are identical up to f32 summation order; exists so that A/B timings
- * can be interleaved inside one process. */
+/* Tuning hook: which kernel mmf_gemm_grouped dispatches to (0 automatic [default]; 2 LDS-DMA ring 256x128; 4 LDS-DMA ring
+ * 256x256 [NT / NN; TN: 2]; 5 256x128 with a 32-deep k-step and two workgroups per CU [NT / NN; TN: 2]).  Automatic picks per
+ * launch from the tile count and K (gemm.hip auto_impl).  1 and 3 (rounds 1-2: register-staged 128x128, persistent ring) were
+ * removed in round 3 and are refused with MMF_E_SHAPE.  Results are identical up to f32 summation order; exists so that A/B
+ * timings can be interleaved inside one process. */
 int mmf_gemm_select_impl(int impl);
 /* the kernel generation the calling thread's last mmf_gemm_grouped[_ex] call dispatched to (profiling labels) */
 int mmf_gemm_last_impl(void);
@@ -168,14 +168,8 @@ int mmf_attn_bwd_grouped(const mmf_attn_problem* problems, int num_problems, int
  * the backward kernels regenerate the same mask from (*rng_state, site, problem, b, h, q, key). */
 int mmf_attn_fwd_grouped_ex(const mmf_attn_problem* problems, int num_problems, int head_dim, float scale,
                             float dropout_p, const uint64_t* rng_state, uint32_t site, void* stream);
-/* Tuning hook: attention kernel generation (0 automatic [default] = 2; 1 register-staged, 128 query rows per
- * workgroup; 2 LDS-DMA ring, 128 query rows per workgroup, XCD-aware order, three workgroups per CU; 3 = forward only:
- * one wave per SIMD, 512 registers, QK^T of tile j+1 software-pipelined under the softmax of tile j — faster per
- * workgroup, slower per CU than 2 at the MulT shapes; 4 = forward only: 8-wave workgroups whose two waves per SIMD
- * alternate matrix and softmax phases between barriers (attention4.hip; equal to 2 at Tk = 2048, slower at the MulT
- * lengths, kept selectable for tuning; MMF_ATTN_FWD_GEN=4 makes it the automatic choice).  1 and 3 exist only in
- * `make LEGACY=1` builds.  Same results up to f32 summation order and the deferred running maximum; exists so that
- * A/B timings can be interleaved inside one process. */
+/* Tuning hook kept for ABI stability: 0 (automatic) and 2 select attention2.hip, the only implementation since round 3
+ * (LDS-DMA ring, 128 query rows per workgroup, XCD-aware order); any other value is refused with MMF_E_SHAPE. */
 int mmf_attn_select_impl(int impl);
 int mmf_attn_bwd_grouped_ex(const mmf_attn_problem* problems, int num_problems, int head_dim, float scale,
                             float dropout_p, const uint64_t* rng_state, uint32_t site, void* stream);
