@@ -225,6 +225,9 @@ _SYMBOL = {"gemm4_grouped_kernel<NT,bf16>": ["gemm4_grouped_kernel<false, false,
            "gemm2_grouped_kernel<NN,bf16>": ["gemm2_grouped_kernel<false, true, false>"],
            "gemm5_grouped_kernel<NN,bf16>": ["gemm5_grouped_kernel<false, true, false>"],
            "gemm2_grouped_kernel<TN,f32>": ["gemm2_grouped_kernel<true, true, true>"],
+           "gemm6_grouped_kernel<TN,f32>": ["gemm6_grouped_kernel<true, true, 32, 4, true>"],
+           "gemm6_grouped_kernel<NT,bf16>": ["gemm6_grouped_kernel<false, false, 32, 4, false>"],
+           "gemm6_grouped_kernel<NN,bf16>": ["gemm6_grouped_kernel<false, true, 32, 4, false>"],
            "attn_fwd_kernel<96>": ["attn_fwd2n_kernel<96, false>", "attn_fwd2_kernel<96, false, 2>", "attn_fwd2_kernel<96, false>"],
            "attn_bwd_kernels<96>": ["attn_bwd_dq2_kernel<96, false>", "attn_bwd_dkv2_kernel<96, false>"]}
 

@@ -13,6 +13,7 @@
 // LDS-DMA pieces exactly, and a wave-private 32-row slice (prologue loads, epilogue stores) is a quarter of a stage.
 #pragma once
 #include "mmf_internal.h"
+#include "lds_image.h"
 
 namespace {
 
@@ -35,11 +36,7 @@ __device__ __forceinline__ float half_sum(float x) {
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
-// ---- the LDS image -----------------------------------------------------------------------------------------------
-template <int DH>
-__device__ __forceinline__ constexpr int img_off(int row, int ch) {
-  return (DH / 32) * 512 * (row >> 3) + 512 * (ch >> 2) + 64 * (row & 7) + 16 * ((ch & 3) ^ ((row >> 2) & 3));
-}
+// ---- the LDS image: img_off<DH>(row, ch) in lds_image.h (shared with gemm6.hip) ------------------------------------
 template <int DH> constexpr int img_tile_bytes() { return 64 * DH * 2; }     // one 64-row tile
 template <int DH> constexpr int img_slice_bytes() { return 32 * DH * 2; }    // one wave's 32-row slice
 

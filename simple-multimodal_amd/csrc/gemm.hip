@@ -6,7 +6,8 @@
 // has >> 256 workgroups even though each problem is small).  The problem table travels by value
 // in the kernel arguments, so a launch is self-contained and hipGraph-capturable.
 //
-// Kernels: gemm2.hip (LDS-DMA ring, 256 x 128 tile: wgrad and long-K NT), gemm4.hip (256 x 256 tile), gemm5.hip (256 x 128, 32-deep k-step, two workgroups per CU).  Rounds 1-2 kept a first-generation 128 x 128
+// Kernels: gemm2.hip (LDS-DMA ring, 256 x 128 tile: long-K NT), gemm4.hip (256 x 256 tile), gemm5.hip (256 x 128, 32-deep k-step, two workgroups per CU),
+// gemm6.hip (256 x 256 tile, one wave per SIMD with 128 x 128 wave tiles: wgrad).  Rounds 1-2 kept a first-generation 128 x 128
 // register-staged kernel here and a persistent variant in gemm3.hip behind mmf_gemm_select_impl(1 / 3); round 3
 // removed them (git history has them, DESIGN.md section 5 their measurements).
 #include "mmf_internal.h"
@@ -15,21 +16,21 @@
 int mmf_gemm2_launch(const mmf_gemm_problem* problems, int num_problems, int layout, int epilogue,
                      int out_f32, const mmf_gemm_extra* extra, hipStream_t s);   // gemm2.hip: LDS-DMA ring kernel
 
-#ifdef MMF_LEGACY_KERNELS
-int mmf_gemm3_launch(const mmf_gemm_problem* problems, int num_problems, int layout, int epilogue,
-                     int out_f32, hipStream_t s);      // gemm3.hip: persistent LDS-DMA ring kernel
-#endif
 int mmf_gemm4_launch(const mmf_gemm_problem* problems, int num_problems, int layout, int epilogue,
                      int out_f32, const mmf_gemm_extra* extra, hipStream_t s);   // gemm4.hip: 256x256 tile
 int mmf_gemm5_launch(const mmf_gemm_problem* problems, int num_problems, int layout, int epilogue,
                      int out_f32, const mmf_gemm_extra* extra, hipStream_t s);   // gemm5.hip: NT, 32-deep k-step, 2 workgroups / CU
+int mmf_gemm6_launch(const mmf_gemm_problem* problems, int num_problems, int layout, int epilogue,
+                     int out_f32, const mmf_gemm_extra* extra, hipStream_t s);   // gemm6.hip: one wave per SIMD, 128x128 wave tiles
+bool mmf_gemm6_supports(const mmf_gemm_problem* problems, int num_problems, int layout);
+bool mmf_gemm6_supports_epi(int epilogue, int out_f32);
 
 // Implementation switch (A/B runs in one process: tools/gemm_bench.py): 0 = automatic (default), 1 =
 // register-staged 128x128 kernel of this file, 2 = 256x128 LDS-DMA ring (gemm2.hip), 3 = its persistent
 // form (gemm3.hip), 4 = 256x256 LDS-DMA ring (gemm4.hip).  Default from MMF_GEMM_IMPL, else automatic.
 static int g_gemm_impl = [] {
   const char* e = getenv("MMF_GEMM_IMPL");
-  int v = (e && e[0] >= '0' && e[0] <= '5') ? e[0] - '0' : 0;
+  int v = (e && e[0] >= '0' && e[0] <= '6') ? e[0] - '0' : 0;
   if (v == 1 || v == 3) v = 0;
   return v;
 }();
@@ -44,9 +45,10 @@ static const int g_shortk_nn = [] { const char* e = getenv("MMF_GEMM_SHORTK_NN")
 // MMF_GEMM_POLICY: 1 = round 1's rule (below), 2 = round 2's rule from the per-group microbenchmarks
 // (profiles/r02_gemm_generations.txt: every MulT launch group x {256x128, 256x256, 256x128/32-deep} in isolation).
 static const int g_tn5 = [] { const char* e = getenv("MMF_GEMM_TN5"); return e ? atoi(e) : 0; }();   // wgrad on the 32-deep two-workgroups-per-CU kernel
+static const int g_tn6 = [] { const char* e = getenv("MMF_GEMM_TN6"); return e ? atoi(e) : 1; }();    // wgrad on the one-wave-per-SIMD kernel (round 3 default; 0: the 256x128 ring)
 static const int g_policy = [] { const char* e = getenv("MMF_GEMM_POLICY"); return e ? atoi(e) : 2; }();
 static int auto_impl(const mmf_gemm_problem* p, int n, int layout) {
-  if (layout == MMF_GEMM_TN) return g_tn5 ? 5 : 2;
+  if (layout == MMF_GEMM_TN) return g_tn5 ? 5 : (g_tn6 && mmf_gemm6_supports(p, n, layout)) ? 6 : 2;
   long tiles = 0;
   int kmax = 0;
   for (int i = 0; i < n; ++i) {
@@ -80,9 +82,9 @@ static int gemm_impl() { return g_gemm_impl; }
 static thread_local int t_last_impl = 0;
 extern "C" int mmf_gemm_last_impl(void) { return t_last_impl; }
 extern "C" int mmf_gemm_select_impl(int impl) {
-  if (impl < 0 || impl > 5) MMF_FAIL(MMF_E_UNSUPPORTED, "mmf_gemm_select_impl: %d not in 0..5", impl);
+  if (impl < 0 || impl > 6) MMF_FAIL(MMF_E_UNSUPPORTED, "mmf_gemm_select_impl: %d not in 0..6", impl);
   if (impl == 1 || impl == 3)
-    MMF_FAIL(MMF_E_UNSUPPORTED, "mmf_gemm_select_impl: generation %d was removed in round 3 (built: 2, 4, 5)", impl);
+    MMF_FAIL(MMF_E_UNSUPPORTED, "mmf_gemm_select_impl: generation %d was removed in round 3 (built: 2, 4, 5, 6)", impl);
   g_gemm_impl = impl;
   return MMF_OK;
 }
@@ -105,14 +107,13 @@ extern "C" int mmf_gemm_grouped_ex(const mmf_gemm_problem* problems, int num_pro
     MMF_FAIL(MMF_E_UNSUPPORTED, "mmf_gemm_grouped: MASK_AUX and ADD_AUX are exclusive");
   if ((epilogue & MMF_EPI_COLSUM_A) && (layout != MMF_GEMM_TN || (epilogue & MMF_EPI_BIAS)))
     MMF_FAIL(MMF_E_UNSUPPORTED, "mmf_gemm_grouped: COLSUM_A is a TN (wgrad) epilogue and excludes BIAS");
-  const bool needs_v2 = extra && (extra->alpha != 1.f || (epilogue & MMF_EPI_DROPOUT));
   if (epilogue & MMF_EPI_DROPOUT) {
     if (!extra || !extra->rng_state || !(extra->dropout_p >= 0.f) || extra->dropout_p >= 1.f)
       MMF_FAIL(MMF_E_SHAPE, "mmf_gemm_grouped_ex: MMF_EPI_DROPOUT needs rng_state and 0 <= p < 1");
   }
   int impl = gemm_impl();
   if (impl == 0) impl = auto_impl(problems, num_problems, layout);
-  if (needs_v2 && impl != 4 && impl != 5) impl = 2;   // only gemm2 / gemm4 / gemm5 have the alpha / dropout epilogue
+  if (impl == 6 && !(mmf_gemm6_supports(problems, num_problems, layout) && mmf_gemm6_supports_epi(epilogue, out_f32))) impl = auto_impl(problems, num_problems, layout);
   t_last_impl = impl;
   for (int i = 0; i < num_problems; ++i) {
     const mmf_gemm_problem& p = problems[i];
@@ -140,5 +141,6 @@ extern "C" int mmf_gemm_grouped_ex(const mmf_gemm_problem* problems, int num_pro
   if (impl == 2) return mmf_gemm2_launch(problems, num_problems, layout, epilogue, out_f32, extra, s);
   if (impl == 4) return mmf_gemm4_launch(problems, num_problems, layout, epilogue, out_f32, extra, s);
   if (impl == 5) return mmf_gemm5_launch(problems, num_problems, layout, epilogue, out_f32, extra, s);
-  MMF_FAIL(MMF_E_UNSUPPORTED, "mmf_gemm_grouped: kernel generation %d is not built (2, 4, 5)", impl);
+  if (impl == 6) return mmf_gemm6_launch(problems, num_problems, layout, epilogue, out_f32, extra, s);
+  MMF_FAIL(MMF_E_UNSUPPORTED, "mmf_gemm_grouped: kernel generation %d is not built (2, 4, 5, 6)", impl);
 }

@@ -1,0 +1,527 @@
+// Grouped bf16 GEMM, ONE WAVE PER SIMD form (round 3): 256 x 256 tile, 4 waves as 2 (m) x 2 (n), each wave 128 x 128 =
+// 4 x 4 tiles of v_mfma_f32_32x32x16_bf16 with the 256 accumulator registers in the AGPR half of a 512-register wave.
+//
+// Why another kernel.  The 8-wave ring kernels (gemm2 / gemm4 / gemm5) spend 2,770-2,900 cycles per k-step for 1,024 (256 x 128)
+// or 2,048 (256 x 256) cycles of MFMA: after the k-step's barrier every wave issues its LDS-DMA pieces (the CU's fill path moves
+// ~60 B/clk, so the burst blocks all eight instruction streams for ~800-1,000 cycles), then every wave reads fragments, then the
+// two waves of a SIMD take turns on the matrix pipe — the CU's three resources are used one after the other.  Here
+//   * a wave owns its SIMD: nothing it does can be covered by a partner, so its stream is software-pipelined by hand: the
+//     fragments of k-substep g+1 are requested before the MFMAs of substep g, the LDS-DMA pieces of a later stage go out one per
+//     MFMA, and the stage hand-over (counted vmcnt, one s_barrier) sits in the middle of the last substep's MFMAs;
+//   * the 128 x 128 wave tile needs 8 fragments per 16 MFMAs (the 128 x 64 tile of gemm4: 12; gemm2's 64 x 64: 16) — a third
+//     fewer LDS bytes per MFMA;
+//   * every fragment read is inline asm (ds_read_b128 / ds_read_b64_tr_b16) behind counted lgkmcnt waits tied to the destination
+//     registers: the compiler's LDS-DMA alias bookkeeping never drains the ring.
+// LDS: a ring of NS stages of BK k-columns; a stage holds the m-operand tile and the n-operand tile in the image of lds_image.h —
+// [256][BK] for an operand whose reduction index is contiguous in memory (x[m][k], W[n][k]; row reads), [BK][256] for one whose
+// reduction index is the memory row (W[k][n], dy[k][m], x[k][n]; transposed reads in the standard MFMA k order, so the two kinds mix).
+// n rides the MFMA row / register axis (first operand = n-fragment): a lane holds 4 consecutive n of one output row.
+#include "mmf_internal.h"
+#include "lds_image.h"
+#include <stdlib.h>
+#include <type_traits>
+
+namespace {
+
+constexpr int BM = 256, BN = 256;
+constexpr int NTHREADS = 256;
+
+struct GemmArgs {
+  int nprob;
+  int epi;
+  int xcd_granule;                   // mmf_xcd_tile()
+  float alpha;                       // multiplies the result after the mask step
+  unsigned drop_thresh, site;        // MMF_EPI_DROPOUT
+  const unsigned long long* rng_state;
+  int tile_start[MMF_GEMM_MAX_PROBLEMS + 1];
+  mmf_gemm_problem p[MMF_GEMM_MAX_PROBLEMS];
+};
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+template <int N> __device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// ---- fragment reads (inline asm; see the header comment) -----------------------------------------------------------------
+template <int OFF>
+__device__ __forceinline__ u32x4_t lds_read_b128(unsigned addr) {
+  u32x4_t r;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+  return r;
+}
+template <int OFF>
+__device__ __forceinline__ u32x2_t lds_read_tr(unsigned addr) {
+  u32x2_t r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+  return r;
+}
+
+// One operand's four fragments of a k-substep.  KC: lane (r = l & 31, h = l >> 5) reads chunk 2 G + h of tile row 32 D + r;
+// KR: two transposed reads give it rows 16 G + 8 h + 0..7 of tile column 32 D + r (the standard MFMA k order).
+template <bool KR> struct Frag4;
+template <> struct Frag4<false> {
+  u32x4_t v[4];
+  // lane parts of the address for even / odd G
+  static __device__ __forceinline__ void lane_parts(int W, int lane, unsigned& a0, unsigned& a1) {
+    const int r = lane & 31, h = lane >> 5, s = (r >> 2) & 3;
+    const unsigned base = (unsigned)((W / 32) * 512 * (r >> 3) + 64 * (r & 7));
+    a0 = base + 16u * (unsigned)(h ^ s);
+    a1 = base + 16u * (unsigned)((2 + h) ^ s);
+  }
+  template <int W, int G, int D0>
+  __device__ __forceinline__ void issue(unsigned t0, unsigned t1) {          // t0 / t1: tile base + lane part for even / odd G
+    const unsigned t = (G & 1) ? t1 : t0;
+    constexpr int S = (W / 32) * 2048;                                       // 32 tile rows
+    v[0] = lds_read_b128<S * (D0 + 0) + 512 * (G >> 1)>(t);
+    v[1] = lds_read_b128<S * (D0 + 1) + 512 * (G >> 1)>(t);
+    v[2] = lds_read_b128<S * (D0 + 2) + 512 * (G >> 1)>(t);
+    v[3] = lds_read_b128<S * (D0 + 3) + 512 * (G >> 1)>(t);
+  }
+  template <int W, int G, int D0, int I>
+  __device__ __forceinline__ void issue1(unsigned t0, unsigned t1) {
+    v[I] = lds_read_b128<(W / 32) * 2048 * (D0 + I) + 512 * (G >> 1)>((G & 1) ? t1 : t0);
+  }
+  __device__ __forceinline__ bf16x8_t get(int i) const { return __builtin_bit_cast(bf16x8_t, v[i]); }
+};
+template <> struct Frag4<true> {
+  u32x2_t lo[4], hi[4];
+  static __device__ __forceinline__ void lane_parts(int, int lane, unsigned& a0, unsigned& a1) {
+    const int h = lane >> 5, g = (lane >> 4) & 1, q = (lane >> 2) & 3, p = lane & 3;
+    const unsigned c = (unsigned)(2 * g + (p >> 1));
+    a0 = (unsigned)(4096 * h + 64 * q) + 16u * (c ^ (unsigned)(2 * h)) + 8u * (unsigned)(p & 1);
+    a1 = (unsigned)(4096 * h + 64 * (4 + q)) + 16u * (c ^ (unsigned)(2 * h + 1)) + 8u * (unsigned)(p & 1);
+  }
+  template <int W, int G, int D0>
+  __device__ __forceinline__ void issue(unsigned t0, unsigned t1) {          // t0 / t1: tile base + lane part of the lo / hi read
+    lo[0] = lds_read_tr<8192 * G + 512 * (D0 + 0)>(t0); hi[0] = lds_read_tr<8192 * G + 512 * (D0 + 0)>(t1);
+    lo[1] = lds_read_tr<8192 * G + 512 * (D0 + 1)>(t0); hi[1] = lds_read_tr<8192 * G + 512 * (D0 + 1)>(t1);
+    lo[2] = lds_read_tr<8192 * G + 512 * (D0 + 2)>(t0); hi[2] = lds_read_tr<8192 * G + 512 * (D0 + 2)>(t1);
+    lo[3] = lds_read_tr<8192 * G + 512 * (D0 + 3)>(t0); hi[3] = lds_read_tr<8192 * G + 512 * (D0 + 3)>(t1);
+  }
+  template <int W, int G, int D0, int I>
+  __device__ __forceinline__ void issue1(unsigned t0, unsigned t1) {
+    lo[I] = lds_read_tr<8192 * G + 512 * (D0 + I)>(t0); hi[I] = lds_read_tr<8192 * G + 512 * (D0 + I)>(t1);
+  }
+  __device__ __forceinline__ bf16x8_t get(int i) const {
+    const u32x4_t w = {lo[i][0], lo[i][1], hi[i][0], hi[i][1]};
+    return __builtin_bit_cast(bf16x8_t, w);
+  }
+};
+// lgkmcnt(0) tied to every destination register of the two operands' fragments: no use can be scheduled above it
+__device__ __forceinline__ void frag_wait(Frag4<false>& a, Frag4<false>& b) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a.v[0]), "+v"(a.v[1]), "+v"(a.v[2]), "+v"(a.v[3]), "+v"(b.v[0]), "+v"(b.v[1]), "+v"(b.v[2]), "+v"(b.v[3]));
+}
+__device__ __forceinline__ void frag_wait(Frag4<false>& a, Frag4<true>& b) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a.v[0]), "+v"(a.v[1]), "+v"(a.v[2]), "+v"(a.v[3]), "+v"(b.lo[0]), "+v"(b.lo[1]), "+v"(b.lo[2]), "+v"(b.lo[3]),
+               "+v"(b.hi[0]), "+v"(b.hi[1]), "+v"(b.hi[2]), "+v"(b.hi[3]));
+}
+__device__ __forceinline__ void frag_wait(Frag4<true>& a, Frag4<true>& b) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a.lo[0]), "+v"(a.lo[1]), "+v"(a.lo[2]), "+v"(a.lo[3]), "+v"(a.hi[0]), "+v"(a.hi[1]), "+v"(a.hi[2]), "+v"(a.hi[3]),
+               "+v"(b.lo[0]), "+v"(b.lo[1]), "+v"(b.lo[2]), "+v"(b.lo[3]), "+v"(b.hi[0]), "+v"(b.hi[1]), "+v"(b.hi[2]), "+v"(b.hi[3]));
+}
+
+// per-lane source offset (bytes, relative to the operand tile's first element at k = 0) of 1-KiB piece p: the inverse of the image
+template <bool KR, int BK>
+__device__ __forceinline__ unsigned piece_voff(int p, int ld, int lane) {
+  constexpr int NC = (KR ? 256 : BK) / 32;
+  const int st = 2 * p + (lane >> 5), rg = st / NC, cc = st % NC;
+  const int w = lane & 31, row = 8 * rg + (w >> 2), ch = 4 * cc + ((w & 3) ^ ((row >> 2) & 3));
+  return (unsigned)(row * ld * 2 + ch * 16);
+}
+
+// tile t of problem P -> (m0, n0): super-rows of 8 m-tiles, n fastest across a super-row (gemm4.hip)
+__device__ __forceinline__ void tile_origin(const mmf_gemm_problem& P, const int t, int& m0, int& n0) {
+  constexpr int GROUP_M = 8;
+  const int tiles_m = (P.M + BM - 1) / BM, tiles_n = (P.N + BN - 1) / BN;
+  const int grp = t / (GROUP_M * tiles_n), rem = t % (GROUP_M * tiles_n);
+  const int gm = min(GROUP_M, tiles_m - grp * GROUP_M);
+  m0 = (grp * GROUP_M + rem % gm) * BM;
+  n0 = (rem / gm) * BN;
+}
+
+// epilogue: lane owns C[m][n .. n+3] for m = m_base + 32 tm + (l & 31), n = n_base + 32 tn + 8 g + 4 (l >> 5).
+// A wave that owns its SIMD has nobody to cover a load's round trip, and the compiler may not move a load above an earlier store
+// to C: the first form of this epilogue (gemm4's: bias / aux / old-C loads next to each use) spent ~35 us per tile in 64 exposed
+// round trips.  Everything it reads is therefore requested up front: the bias once, and per 32-row block tm the aux row pieces /
+// old C values of block tm + 1 before block tm is finished and stored.
+template <bool OUT_F32>
+__device__ __forceinline__ void tile_epilogue(const GemmArgs& args, const mmf_gemm_problem& P, const int pi, const int mb, const int nb,
+                                              f32x16_t (&acc)[4][4], const int lane) {
+  const int M = P.M, N = P.N;
+  const int epi = args.epi;
+  const unsigned short* __restrict__ aux = static_cast<const unsigned short*>(P.aux);
+  const bool do_drop = epi & MMF_EPI_DROPOUT;
+  const unsigned drop_key = do_drop ? mmf_rng_key(*args.rng_state, args.site, (unsigned)pi) : 0u;
+  const float drop_scale = do_drop ? 1.f / (1.f - (float)args.drop_thresh * (1.f / 4294967296.f)) : 1.f;
+  const float alpha = args.alpha;
+  const bool use_aux = epi & (MMF_EPI_MASK_AUX | MMF_EPI_ADD_AUX);
+  const bool use_old = OUT_F32 && (epi & MMF_EPI_ACCUM);
+  const int h = lane >> 5;
+  auto ncol = [&](int tn, int g) { return nb + 32 * tn + 8 * g + 4 * h; };
+
+  f32x4_t bv[4][4];
+#pragma unroll
+  for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      bv[tn][g] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      if ((epi & MMF_EPI_BIAS) && ncol(tn, g) < N) bv[tn][g] = *reinterpret_cast<const f32x4_t*>(P.bias + ncol(tn, g));
+    }
+  auto finish = [&](f32x4_t v, const f32x4_t& b, const u32x2_t& a, int m, int n) -> f32x4_t {  // bias -> relu -> dropout -> mask -> alpha -> residual
+    v += b;
+    if (epi & MMF_EPI_RELU) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+    }
+    if (do_drop) {
+      const unsigned idx = (unsigned)m * (unsigned)N + (unsigned)n;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = mmf_keep(drop_key, idx + e, args.drop_thresh) ? v[e] * drop_scale : 0.f;
+    }
+    const float a0 = bf16lo(a[0]), a1 = bf16hi(a[0]), a2 = bf16lo(a[1]), a3 = bf16hi(a[1]);
+    if (epi & MMF_EPI_MASK_AUX) {
+      v[0] = a0 > 0.f ? v[0] : 0.f; v[1] = a1 > 0.f ? v[1] : 0.f;
+      v[2] = a2 > 0.f ? v[2] : 0.f; v[3] = a3 > 0.f ? v[3] : 0.f;
+    }
+    v *= alpha;
+    if (epi & MMF_EPI_ADD_AUX) { v[0] += a0; v[1] += a1; v[2] += a2; v[3] += a3; }
+    return v;
+  };
+  const bool wide = (N & 7) == 0 && (P.ldc & 7) == 0;
+  if constexpr (OUT_F32) {
+    // f32 output (wgrad; the f32 heads), one 32 x 32 tile at a time: the old values of tile t + 1 are requested before tile t is
+    // stored.  The aux forms are not offered here: mmf_gemm6_launch refuses them with f32 output.
+    f32x4_t oldv[2][4];
+    auto preload_tile = [&](int t, int slot) {
+      const int tm = t >> 2, tn = t & 3, m = mb + 32 * tm + (lane & 31);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        oldv[slot][g] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        if (m < M && ncol(tn, g) < N)
+          oldv[slot][g] = *reinterpret_cast<const f32x4_t*>(static_cast<const float*>(P.C) + (size_t)m * P.ldc + ncol(tn, g));
+      }
+    };
+    if (use_old) preload_tile(0, 0);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int tm = t >> 2, tn = t & 3, m = mb + 32 * tm + (lane & 31);
+      f32x4_t v[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        v[g] = f32x4_t{acc[tn][tm][4 * g], acc[tn][tm][4 * g + 1], acc[tn][tm][4 * g + 2], acc[tn][tm][4 * g + 3]};
+        v[g] = finish(v[g], bv[tn][g], u32x2_t{0u, 0u}, m, ncol(tn, g));
+        if (use_old) v[g] += oldv[t & 1][g];
+      }
+      if (use_old && t + 1 < 16) preload_tile(t + 1, (t + 1) & 1);
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        if (m < M && ncol(tn, g) < N)
+          *reinterpret_cast<f32x4_t*>(static_cast<float*>(P.C) + (size_t)m * P.ldc + ncol(tn, g)) = v[g];
+    }
+  } else {
+    // bf16 output, one 32 x 32 tile at a time, tile t + 1's aux pieces requested before tile t is stored
+    u32x2_t axv[2][4];
+    auto preload_tile = [&](int t, int slot) {
+      const int tm = t >> 2, tn = t & 3, m = mb + 32 * tm + (lane & 31);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        axv[slot][g] = u32x2_t{0u, 0u};
+        if (m < M && ncol(tn, g) < N) axv[slot][g] = *reinterpret_cast<const u32x2_t*>(aux + (size_t)m * P.ldaux + ncol(tn, g));
+      }
+    };
+    if (use_aux) preload_tile(0, 0);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int tm = t >> 2, tn = t & 3, m = mb + 32 * tm + (lane & 31);
+      u32x2_t o[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4_t v = {acc[tn][tm][4 * g], acc[tn][tm][4 * g + 1], acc[tn][tm][4 * g + 2], acc[tn][tm][4 * g + 3]};
+        v = finish(v, bv[tn][g], use_aux ? axv[t & 1][g] : u32x2_t{0u, 0u}, m, ncol(tn, g));
+        o[g] = u32x2_t{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+      }
+      if (use_aux && t + 1 < 16) preload_tile(t + 1, (t + 1) & 1);
+      if (wide) {
+        // 16-byte stores: the 8-byte pieces of register groups g and g + 1 are exchanged between the half-waves
+        // (v_permlane32_swap), so lanes 0-31 hold 8 consecutive columns of group 2 gp and lanes 32-63 of group 2 gp + 1
+#pragma unroll
+        for (int gp = 0; gp < 2; ++gp) {
+          const auto r0 = __builtin_amdgcn_permlane32_swap(o[2 * gp][0], o[2 * gp + 1][0], false, false);
+          const auto r1 = __builtin_amdgcn_permlane32_swap(o[2 * gp][1], o[2 * gp + 1][1], false, false);
+          const u32x4_t w = {r0[0], r1[0], r0[1], r1[1]};
+          const int n = nb + 32 * tn + 16 * gp + 8 * h;
+          if (m < M && n < N)
+            *reinterpret_cast<u32x4_t*>(static_cast<unsigned short*>(P.C) + (size_t)m * P.ldc + n) = w;
+        }
+      } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          if (m < M && ncol(tn, g) < N)
+            *reinterpret_cast<u32x2_t*>(static_cast<unsigned short*>(P.C) + (size_t)m * P.ldc + ncol(tn, g)) = o[g];
+      }
+    }
+  }
+}
+
+// the whole kernel as a device function (the __global__ wrapper below only owns the LDS): with the inline-asm reads reachable
+// directly from a __global__ template hipcc's host pass dropped the kernel's launch stub without a diagnostic
+template <bool A_KR, bool B_KR, int BK, int NS, bool OUT_F32>
+__device__ __forceinline__ void gemm6_body(const GemmArgs& args, const int total_tiles, char* smem) {
+  constexpr int TILE = 256 * BK * 2, STAGE = 2 * TILE, NG = BK / 16, PPO = BK / 8, PPW = 2 * PPO;
+  constexpr int WA = A_KR ? 256 : BK, WB = B_KR ? 256 : BK;
+  static_assert(NG == 2 || NG == 4, "BK is 32 or 64");
+
+  const int bid = mmf_xcd_tile(blockIdx.x, total_tiles, args.xcd_granule);
+  int pi = 0;
+  while (pi + 1 < args.nprob && bid >= args.tile_start[pi + 1]) ++pi;
+  const mmf_gemm_problem& P = args.p[pi];
+  int m0, n0;
+  tile_origin(P, bid - args.tile_start[pi], m0, n0);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;                   // this wave's 128 x 128 quadrant
+  const int M = P.M, N = P.N, K = P.K;
+  const int KT = (K + BK - 1) / BK;                          // a KR operand's rows past K read as zeros (range check); KC operands: K % BK == 0 (host)
+
+  // ---- LDS-DMA: this wave's PPW pieces of a stage (PPO of the m-operand tile, PPO of the n-operand tile), offsets once --------
+  unsigned voff[PPW];
+#pragma unroll
+  for (int i = 0; i < PPO; ++i) {
+    voff[i] = piece_voff<A_KR, BK>(wave + 4 * i, P.lda, lane);
+    voff[PPO + i] = piece_voff<B_KR, BK>(wave + 4 * i, P.ldb, lane);
+  }
+  const unsigned short* Ab = static_cast<const unsigned short*>(P.A) + (A_KR ? (size_t)m0 : (size_t)m0 * P.lda);
+  const unsigned short* Bb = static_cast<const unsigned short*>(P.B) + (B_KR ? (size_t)n0 : (size_t)n0 * P.ldb);
+  // bytes from the tile's first element to the matrix' LAST VALID element (range check: rows past the matrix read as zeros).
+  // Not "rows x ld": the tile is fetched without a column predicate, and behind the last row's valid columns there may be nothing
+  // mapped (a column-slice view of a packed buffer that ends on its allocation's last page).
+  const long recA = A_KR ? ((long)(K - 1) * P.lda + (M - m0)) * 2 : ((long)(M - m0 - 1) * P.lda + K) * 2;
+  const long recB = B_KR ? ((long)(K - 1) * P.ldb + (N - n0)) * 2 : ((long)(N - n0 - 1) * P.ldb + K) * 2;
+  const int kstepA = A_KR ? BK * P.lda : BK, kstepB = B_KR ? BK * P.ldb : BK;     // elements per k-step
+  char* const my_pieces = smem + wave * 1024;
+
+  auto issue_piece = [&](int kt, int i) {                    // piece i of this wave for stage kt (wave-uniform control)
+    char* st = my_pieces + (kt % NS) * STAGE;
+    if (i < PPO) {
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<unsigned short*>(Ab + (size_t)kt * kstepA), 0, (int)(recA - (long)kt * kstepA * 2), 0x00020000);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(st + i * 4096), 16, voff[i], 0, 0, 0);
+    } else {
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<unsigned short*>(Bb + (size_t)kt * kstepB), 0, (int)(recB - (long)kt * kstepB * 2), 0x00020000);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(st + TILE + (i - PPO) * 4096), 16, voff[i], 0, 0, 0);
+    }
+  };
+
+  // ---- fragment addressing ------------------------------------------------------------------------------------------------------
+  unsigned la0, la1, lb0, lb1;
+  Frag4<A_KR>::lane_parts(WA, lane, la0, la1);
+  Frag4<B_KR>::lane_parts(WB, lane, lb0, lb1);
+  const unsigned smem_base = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)smem;
+  // the wave's quadrant inside an operand tile: 128 tile rows (KC) or 128 tile columns (KR) = D blocks 4 w .. 4 w + 3
+  const unsigned qa = (unsigned)(A_KR ? 512 * 4 * wm : (WA / 32) * 2048 * 4 * wm);
+  const unsigned qb = (unsigned)(B_KR ? 512 * 4 * wn : (WB / 32) * 2048 * 4 * wn);
+  la0 += smem_base + qa; la1 += smem_base + qa;
+  lb0 += smem_base + TILE + qb; lb1 += smem_base + TILE + qb;
+
+  f32x16_t acc[4][4];                                         // [tn][tm]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  const bool do_colsum = A_KR && (args.epi & MMF_EPI_COLSUM_A) && n0 == 0 && wn == 0;
+  // wgrad's fused bias gradient (column sums of the m-operand).  The 256 accumulator registers fill the AGPR half exactly: a
+  // seventeenth compiler-visible MFMA accumulator made hipcc keep one tile in VGPRs and shuttle it through AGPRs around every
+  // use (16 v_accvgpr_write + s_nop 11 + 16 v_accvgpr_read per MFMA: TN ran 40 % slower than NT).  So the sums live in ONE
+  // VGPR-resident tile behind inline asm (the VGPR form of the same MFMA): the first operand of block tm's MFMA is a selector
+  // fragment — row tm all ones, every other row zero — so row tm of the tile collects block tm's column sums.
+  const bool edge_m = m0 + BM > M;
+  bool colok[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) colok[j] = m0 + 128 * wm + 32 * j + (lane & 31) < M;
+  f32x16_t csum;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) csum[e] = 0.f;
+  u32x4_t sel[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const unsigned w = ((lane & 31) == j) ? 0x3f803f80u : 0u;
+    sel[j] = u32x4_t{w, w, w, w};
+  }
+
+  // ---- prologue: fill the ring -----------------------------------------------------------------------------------------------------
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+    if (s < KT) {
+#pragma unroll
+      for (int i = 0; i < PPW; ++i) issue_piece(s, i);
+    }
+  if (KT >= NS) vm_wait<PPW * (NS - 1)>(); else vm_wait<0>();
+  __builtin_amdgcn_s_barrier();
+  Frag4<A_KR> fa[2];
+  Frag4<B_KR> fb[2];
+  fa[0].template issue<WA, 0, 0>(la0, la1);
+  fb[0].template issue<WB, 0, 0>(lb0, lb1);
+  frag_wait(fa[0], fb[0]);
+
+  // MFMA i of a substep, (tm, tn) = (i / 4, i % 4); the bias-gradient MFMA rides behind each row's last
+  auto mf = [&](const Frag4<A_KR>& a, const Frag4<B_KR>& b, int i) {
+    const int tm = i >> 2, tn = i & 3;
+    acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b.get(tn), a.get(tm), acc[tn][tm], 0, 0, 0);
+    if (A_KR && do_colsum && tn == 3) {
+      u32x4_t fm = __builtin_bit_cast(u32x4_t, a.get(tm));
+      // columns past M hold whatever lies behind the row in memory; with the selector a NaN there would reach the valid
+      // column of the same lane in the other blocks' rows (0 x NaN), so a boundary tile zeroes them first
+      if (edge_m && !colok[tm]) fm = u32x4_t{0u, 0u, 0u, 0u};
+      asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(csum) : "v"(sel[tm]), "v"(fm));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // read unit u (0..3: m-operand fragments, 4..7: n-operand fragments) of substep G of the stage at byte offset so
+#define MMF_G6_READ(dstA, dstB, G, u, so)                                                              \
+  do {                                                                                                 \
+    if ((u) == 0) dstA.template issue1<WA, G, 0, 0>(la0 + (so), la1 + (so));                            \
+    if ((u) == 1) dstA.template issue1<WA, G, 0, 1>(la0 + (so), la1 + (so));                            \
+    if ((u) == 2) dstA.template issue1<WA, G, 0, 2>(la0 + (so), la1 + (so));                            \
+    if ((u) == 3) dstA.template issue1<WA, G, 0, 3>(la0 + (so), la1 + (so));                            \
+    if ((u) == 4) dstB.template issue1<WB, G, 0, 0>(lb0 + (so), lb1 + (so));                            \
+    if ((u) == 5) dstB.template issue1<WB, G, 0, 1>(lb0 + (so), lb1 + (so));                            \
+    if ((u) == 6) dstB.template issue1<WB, G, 0, 2>(lb0 + (so), lb1 + (so));                            \
+    if ((u) == 7) dstB.template issue1<WB, G, 0, 3>(lb0 + (so), lb1 + (so));                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                 \
+  } while (0)
+  // a substep that is not the stage's last: MFMA i (i < 8) is followed by one read of the next substep's fragments, the other
+  // eight MFMAs cover the reads' latency
+#define MMF_G6_SUBSTEP(cur, nxt, G)                                                                    \
+  do {                                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                                   \
+      mf(fa[cur], fb[cur], i);                                                                         \
+      if (i < 8) MMF_G6_READ(fa[nxt], fb[nxt], G, i, so);                                              \
+    }                                                                                                  \
+    frag_wait(fa[nxt], fb[nxt]);                                                                       \
+  } while (0)
+
+  // One stage.  NEXT: stage kt + 1 exists (hand-over + its first fragments); DMA: stage kt + NS exists (this wave's pieces go out).
+  // Both are compile-time per loop below: a uniform branch costs a wave that owns its SIMD 10-20 idle matrix-pipe cycles, and the
+  // first form of this loop had sixteen of them per stage.
+  auto stage = [&](auto next_c, auto dma_c, const int kt, const int ahead) {
+    constexpr bool NEXT = decltype(next_c)::value, DMA = decltype(dma_c)::value;
+    const unsigned so = (unsigned)((kt % NS) * STAGE);
+    if constexpr (NG == 4) {
+      MMF_G6_SUBSTEP(0, 1, 1);
+      MMF_G6_SUBSTEP(1, 0, 2);
+      MMF_G6_SUBSTEP(0, 1, 3);
+    } else {
+      MMF_G6_SUBSTEP(0, 1, 1);
+    }
+    // last substep: four MFMAs, the stage hand-over, then the rest — MFMAs 4..11 each followed by one read of stage kt + 1's first
+    // fragments, MFMAs 8..15 by this wave's LDS-DMA pieces of stage kt + NS
+    const unsigned sn = (unsigned)(((kt + 1) % NS) * STAGE);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mf(fa[1], fb[1], i);
+    if constexpr (NEXT) {
+      if constexpr (DMA) {
+        vm_wait<PPW * (NS - 2)>();                           // steady state: the NS - 2 younger stages stay in flight
+      } else {                                               // ring running dry: exactly the stages issued after kt + 1
+        if (ahead >= 3) vm_wait<PPW * 3>(); else if (ahead == 2) vm_wait<PPW * 2>(); else if (ahead == 1) vm_wait<PPW>(); else vm_wait<0>();
+      }
+      __builtin_amdgcn_s_barrier();                          // stage kt + 1 landed for everyone; nobody reads stage kt any more
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 4; i < 16; ++i) {
+      mf(fa[1], fb[1], i);
+      if constexpr (NEXT) { if (i < 12) MMF_G6_READ(fa[0], fb[0], 0, i - 4, sn); }
+      if constexpr (DMA) {
+        if (i >= 8) {
+#pragma unroll
+          for (int q = (i - 8) * PPW / 8; q < (i - 7) * PPW / 8; ++q) issue_piece(kt + NS, q);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if constexpr (NEXT) frag_wait(fa[0], fb[0]);
+  };
+  using T = std::true_type;
+  using F = std::false_type;
+  int kt = 0;
+  for (; kt + NS < KT; ++kt) stage(T{}, T{}, kt, NS - 2);
+  for (; kt + 1 < KT; ++kt) stage(T{}, F{}, kt, min(NS - 2, KT - 2 - kt));
+  stage(F{}, F{}, kt, 0);
+#undef MMF_G6_SUBSTEP
+#undef MMF_G6_READ
+
+  if (A_KR && do_colsum) {              // row tm of the tile (register tm of lanes 0..31) = the sums of block tm's 32 columns
+    asm volatile("s_nop 15\n\ts_nop 7" : "+v"(csum));   // the asm MFMAs are invisible to the hazard recognizer
+    if (lane < 32) {
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm) {
+        const int m = m0 + 128 * wm + 32 * tm + lane;
+        if (m < M) atomicAdd(const_cast<float*>(P.bias) + m, csum[tm]);
+      }
+    }
+  }
+  tile_epilogue<OUT_F32>(args, P, pi, m0 + 128 * wm, n0 + 128 * wn, acc, lane);
+}
+
+template <bool A_KR, bool B_KR, int BK, int NS, bool OUT_F32>
+__global__ __launch_bounds__(NTHREADS, 1)
+void gemm6_grouped_kernel(const GemmArgs args, const int total_tiles) {
+  __shared__ __attribute__((aligned(1024))) char smem[NS * 2 * 256 * BK * 2];
+  gemm6_body<A_KR, B_KR, BK, NS, OUT_F32>(args, total_tiles, smem);
+}
+
+template <bool A_KR, bool B_KR, int BK, int NS>
+void launch(const GemmArgs& a, int total, int out_f32, hipStream_t s) {
+  if (out_f32) hipLaunchKernelGGL((gemm6_grouped_kernel<A_KR, B_KR, BK, NS, true>), dim3(total), dim3(NTHREADS), 0, s, a, total);
+  else         hipLaunchKernelGGL((gemm6_grouped_kernel<A_KR, B_KR, BK, NS, false>), dim3(total), dim3(NTHREADS), 0, s, a, total);
+}
+}  // namespace
+
+// whether gemm6 can take this launch (gemm.hip asks before selecting it): every K a multiple of the stage depth
+bool mmf_gemm6_supports(const mmf_gemm_problem* problems, int num_problems, int layout) {
+  if (layout == MMF_GEMM_TN) return true;                    // both operands KR: the K tail is zero-filled by the range check
+  const int bk = 32;
+  for (int i = 0; i < num_problems; ++i)
+    if (problems[i].K % bk) return false;
+  return true;
+}
+bool mmf_gemm6_supports_epi(int epilogue, int out_f32) { return !(out_f32 && (epilogue & (MMF_EPI_MASK_AUX | MMF_EPI_ADD_AUX))); }
+
+// called by mmf_gemm_grouped (gemm.hip) after validation
+int mmf_gemm6_launch(const mmf_gemm_problem* problems, int num_problems, int layout, int epilogue,
+                     int out_f32, const mmf_gemm_extra* extra, hipStream_t s) {
+  GemmArgs a;
+  a.nprob = num_problems;
+  a.epi = epilogue;
+  a.xcd_granule = mmf_xcd_granule();
+  a.alpha = extra ? extra->alpha : 1.f;
+  a.drop_thresh = extra ? mmf_drop_thresh(extra->dropout_p) : 0u;
+  a.site = extra ? extra->site : 0u;
+  a.rng_state = extra ? reinterpret_cast<const unsigned long long*>(extra->rng_state) : nullptr;
+  int total = 0;
+  for (int i = 0; i < num_problems; ++i) {
+    const mmf_gemm_problem& p = problems[i];
+    const size_t a_bytes = (size_t)(layout == MMF_GEMM_TN ? p.K : p.M) * p.lda * 2;
+    const size_t b_bytes = (size_t)(layout == MMF_GEMM_NT ? p.N : p.K) * p.ldb * 2;
+    if (a_bytes >= 0x7fffffffull || b_bytes >= 0x7fffffffull)
+      MMF_FAIL(MMF_E_UNSUPPORTED, "mmf_gemm_grouped[%d]: operand larger than 2 GiB", i);
+    if (layout != MMF_GEMM_TN && p.K % 32)
+      MMF_FAIL(MMF_E_UNSUPPORTED, "mmf_gemm_grouped[%d]: the one-wave-per-SIMD kernel needs K %% 32 == 0 for NT / NN (K = %d)", i, p.K);
+    if (out_f32 && (epilogue & (MMF_EPI_MASK_AUX | MMF_EPI_ADD_AUX)))
+      MMF_FAIL(MMF_E_UNSUPPORTED, "mmf_gemm_grouped: the one-wave-per-SIMD kernel has no aux epilogue with f32 output");
+    a.tile_start[i] = total;
+    total += ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    a.p[i] = p;
+  }
+  a.tile_start[num_problems] = total;
+  switch (layout) {
+    case MMF_GEMM_NT: launch<false, false, 32, 4>(a, total, out_f32, s); break;
+    case MMF_GEMM_NN: launch<false, true, 32, 4>(a, total, out_f32, s); break;
+    default:          launch<true, true, 32, 4>(a, total, out_f32, s); break;
+  }
+  MMF_CHECK_LAUNCH("mmf_gemm_grouped(v6)");
+  return MMF_OK;
+}
