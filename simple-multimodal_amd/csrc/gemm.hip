@@ -46,15 +46,20 @@ static const int g_shortk_nn = [] { const char* e = getenv("MMF_GEMM_SHORTK_NN")
 // (profiles/r02_gemm_generations.txt: every MulT launch group x {256x128, 256x256, 256x128/32-deep} in isolation).
 static const int g_tn5 = [] { const char* e = getenv("MMF_GEMM_TN5"); return e ? atoi(e) : 0; }();   // wgrad on the 32-deep two-workgroups-per-CU kernel
 static const int g_tn6 = [] { const char* e = getenv("MMF_GEMM_TN6"); return e ? atoi(e) : 1; }();    // wgrad on the one-wave-per-SIMD kernel (round 3 default; 0: the 256x128 ring)
+static const int g_longk6 = [] { const char* e = getenv("MMF_GEMM_LONGK6"); return e ? atoi(e) : 0; }();
 static const int g_policy = [] { const char* e = getenv("MMF_GEMM_POLICY"); return e ? atoi(e) : 2; }();
 static int auto_impl(const mmf_gemm_problem* p, int n, int layout) {
   if (layout == MMF_GEMM_TN) return g_tn5 ? 5 : (g_tn6 && mmf_gemm6_supports(p, n, layout)) ? 6 : 2;
   long tiles = 0;
-  int kmax = 0;
+  int kmax = 0, kmin = 1 << 30;
   for (int i = 0; i < n; ++i) {
     tiles += (long)((p[i].M + 255) / 256) * ((p[i].N + 255) / 256);
     kmax = p[i].K > kmax ? p[i].K : kmax;
+    kmin = p[i].K < kmin ? p[i].K : kmin;
   }
+  // long reductions (FFN2, dX: K = 3072): the one-wave-per-SIMD kernel's per-tile overhead (~8 us against ~3.6) is amortised and its
+  // k-loop is the faster one (MMF_GEMM_LONGK6: minimum K, 0 = never)
+  if (g_longk6 > 0 && kmin >= g_longk6 && mmf_gemm6_supports(p, n, layout)) return 6;
   static const int cus = [] { int c = mmf_device_cu_count(); return c > 0 ? c : 256; }();
   const long rounds = (tiles + cus - 1) / cus;
   if (g_policy >= 2) {

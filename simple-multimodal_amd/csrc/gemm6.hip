@@ -21,6 +21,12 @@
 #include <stdlib.h>
 #include <type_traits>
 
+// MMF_G6_DBG (build-time ablation bits, timing only, results wrong): 1 no LDS-DMA in the loop, 2 no stage hand-over (vmcnt +
+// barrier), 4 no fragment reads in the loop
+#ifndef MMF_G6_DBG
+#define MMF_G6_DBG 0
+#endif
+
 namespace {
 
 constexpr int BM = 256, BN = 256;
@@ -300,17 +306,42 @@ __device__ __forceinline__ void gemm6_body(const GemmArgs& args, const int total
   const int kstepA = A_KR ? BK * P.lda : BK, kstepB = B_KR ? BK * P.ldb : BK;     // elements per k-step
   char* const my_pieces = smem + wave * 1024;
 
-  auto issue_piece = [&](int kt, int i) {                    // piece i of this wave for stage kt (wave-uniform control)
+  auto issue_piece = [&](int kt, int i, bool empty = false) {   // piece i of this wave for stage kt (wave-uniform control); empty: MMF_G6_DBG & 8
     char* st = my_pieces + (kt % NS) * STAGE;
     if (i < PPO) {
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-          const_cast<unsigned short*>(Ab + (size_t)kt * kstepA), 0, (int)(recA - (long)kt * kstepA * 2), 0x00020000);
+          const_cast<unsigned short*>(Ab + (size_t)kt * kstepA), 0, empty ? 0 : (int)(recA - (long)kt * kstepA * 2), 0x00020000);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(st + i * 4096), 16, voff[i], 0, 0, 0);
     } else {
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-          const_cast<unsigned short*>(Bb + (size_t)kt * kstepB), 0, (int)(recB - (long)kt * kstepB * 2), 0x00020000);
+          const_cast<unsigned short*>(Bb + (size_t)kt * kstepB), 0, empty ? 0 : (int)(recB - (long)kt * kstepB * 2), 0x00020000);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(st + TILE + (i - PPO) * 4096), 16, voff[i], 0, 0, 0);
     }
+  };
+
+  // In the loop a piece is TWO instructions (M0, buffer_load ... lds) from inline asm against two descriptors that live in SGPR
+  // quads and are advanced by one k-step per stage (three scalar instructions each).  A wave issues at most one instruction per four
+  // cycles, so a wave that owns its SIMD has eight issue slots per 32-cycle MFMA; the builtin form rebuilt the descriptor quad for
+  // every piece (five to six instructions per piece) and the slots behind the hand-over barrier — MFMA, fragment read, piece — ran
+  // out: the matrix pipe waited ~35 cycles per piece (ablations in DESIGN.md section 5, round 3).
+  typedef int i32x4_t __attribute__((ext_vector_type(4)));
+  auto mkdesc = [](const unsigned short* p, long rec) {
+    const unsigned long long a = (unsigned long long)(uintptr_t)p;
+    return i32x4_t{(int)(unsigned)a, (int)((unsigned)(a >> 32) & 0xffffu), (int)rec, 0x00020000};
+  };
+  auto advance = [](i32x4_t& d, int bytes) {
+    const unsigned long long a = (((unsigned long long)(unsigned)d[1] << 32) | (unsigned)d[0]) + (unsigned long long)bytes;
+    d[0] = (int)(unsigned)a; d[1] = (int)(unsigned)(a >> 32); d[2] -= bytes;
+  };
+  // descriptors of the stage the loop fetches next; stage NS - 1 is the last one the prologue fetched
+  i32x4_t dA = mkdesc(Ab + (size_t)(NS - 1) * kstepA, recA - (long)(NS - 1) * kstepA * 2);
+  i32x4_t dB = mkdesc(Bb + (size_t)(NS - 1) * kstepB, recB - (long)(NS - 1) * kstepB * 2);
+  const unsigned lds_pieces = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)my_pieces;
+  auto hot_piece = [&](auto ic, const unsigned ring_base) {   // piece I of this wave into the ring slot at LDS address ring_base (+ wave)
+    constexpr int I = decltype(ic)::value, OFF = I < PPO ? I * 4096 : TILE + (I - PPO) * 4096;
+    if (I < PPO) asm volatile("s_add_i32 m0, %0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(ring_base), "v"(voff[I]), "s"(dA), "n"(OFF) : "memory");
+    else         asm volatile("s_add_i32 m0, %0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(ring_base), "v"(voff[I]), "s"(dB), "n"(OFF) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
   };
 
   // ---- fragment addressing ------------------------------------------------------------------------------------------------------
@@ -331,7 +362,9 @@ __device__ __forceinline__ void gemm6_body(const GemmArgs& args, const int total
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-  const bool do_colsum = A_KR && (args.epi & MMF_EPI_COLSUM_A) && n0 == 0 && wn == 0;
+  // the tile column n0 == 0 carries the bias gradient; its four waves share the extra MFMAs: wave (wm, wn) sums blocks 2 wn, 2 wn + 1 of
+  // its 128 m-columns (two extra MFMAs per substep in every wave instead of four in two of them: the tile's barrier waits for the slowest)
+  const bool do_colsum = A_KR && (args.epi & MMF_EPI_COLSUM_A) && n0 == 0;
   // wgrad's fused bias gradient (column sums of the m-operand).  The 256 accumulator registers fill the AGPR half exactly: a
   // seventeenth compiler-visible MFMA accumulator made hipcc keep one tile in VGPRs and shuttle it through AGPRs around every
   // use (16 v_accvgpr_write + s_nop 11 + 16 v_accvgpr_read per MFMA: TN ran 40 % slower than NT).  So the sums live in ONE
@@ -370,7 +403,7 @@ __device__ __forceinline__ void gemm6_body(const GemmArgs& args, const int total
   auto mf = [&](const Frag4<A_KR>& a, const Frag4<B_KR>& b, int i) {
     const int tm = i >> 2, tn = i & 3;
     acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b.get(tn), a.get(tm), acc[tn][tm], 0, 0, 0);
-    if (A_KR && do_colsum && tn == 3) {
+    if (A_KR && do_colsum && tn == 3 && (tm >> 1) == wn) {
       u32x4_t fm = __builtin_bit_cast(u32x4_t, a.get(tm));
       // columns past M hold whatever lies behind the row in memory; with the selector a NaN there would reach the valid
       // column of the same lane in the other blocks' rows (0 x NaN), so a boundary tile zeroes them first
@@ -392,23 +425,35 @@ __device__ __forceinline__ void gemm6_body(const GemmArgs& args, const int total
     if ((u) == 7) dstB.template issue1<WB, G, 0, 3>(lb0 + (so), lb1 + (so));                            \
     __builtin_amdgcn_sched_barrier(0);                                                                 \
   } while (0)
+  // LDS-DMA schedule.  Stage kt's ring slot is free from its hand-over barrier on and is refilled with stage kt + NS: four pieces
+  // behind the last four MFMAs of stage kt ("late"), the others behind MFMAs 8, 10, 12, 14 of the not-last substeps of stage
+  // kt + 1 ("early") — slots that carry no fragment read.
+  static_assert(PPW == 4 + 4 * (NG - 1), "four late pieces + four per not-last substep");
   // a substep that is not the stage's last: MFMA i (i < 8) is followed by one read of the next substep's fragments, the other
   // eight MFMAs cover the reads' latency
 #define MMF_G6_SUBSTEP(cur, nxt, G)                                                                    \
   do {                                                                                                 \
     _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                                   \
       mf(fa[cur], fb[cur], i);                                                                         \
-      if (i < 8) MMF_G6_READ(fa[nxt], fb[nxt], G, i, so);                                              \
+      if (i < 8 && !(MMF_G6_DBG & 4)) MMF_G6_READ(fa[nxt], fb[nxt], G, i, so);                        \
+      if (i == 8 && !(MMF_G6_DBG & 1)) { if (early) hot_piece(std::integral_constant<int, 4 * (G)>{}, ring_prev); }      \
+      if (i == 10 && !(MMF_G6_DBG & 1)) { if (early) hot_piece(std::integral_constant<int, 4 * (G) + 1>{}, ring_prev); } \
+      if (i == 12 && !(MMF_G6_DBG & 1)) { if (early) hot_piece(std::integral_constant<int, 4 * (G) + 2>{}, ring_prev); } \
+      if (i == 14 && !(MMF_G6_DBG & 1)) { if (early) hot_piece(std::integral_constant<int, 4 * (G) + 3>{}, ring_prev); } \
     }                                                                                                  \
-    frag_wait(fa[nxt], fb[nxt]);                                                                       \
+    if (!(MMF_G6_DBG & 4)) frag_wait(fa[nxt], fb[nxt]);                                                \
   } while (0)
 
-  // One stage.  NEXT: stage kt + 1 exists (hand-over + its first fragments); DMA: stage kt + NS exists (this wave's pieces go out).
-  // Both are compile-time per loop below: a uniform branch costs a wave that owns its SIMD 10-20 idle matrix-pipe cycles, and the
-  // first form of this loop had sixteen of them per stage.
-  auto stage = [&](auto next_c, auto dma_c, const int kt, const int ahead) {
-    constexpr bool NEXT = decltype(next_c)::value, DMA = decltype(dma_c)::value;
+  using T = std::true_type;
+  using F = std::false_type;
+  // One stage.  NEXT: stage kt + 1 exists (hand-over + its first fragments).  STEADY: both refills (stage kt - 1 + NS early,
+  // stage kt + NS late) exist and no condition is evaluated — a uniform branch costs a wave that owns its SIMD 10-20 idle
+  // matrix-pipe cycles; the few stages at the ends of the sweep take the checked form.
+  auto stage = [&](auto next_c, auto steady_c, const int kt, const int ahead, const bool e, const bool l) {
+    constexpr bool NEXT = decltype(next_c)::value, STEADY = decltype(steady_c)::value;
+    const bool early = STEADY || e, late = STEADY || l;
     const unsigned so = (unsigned)((kt % NS) * STAGE);
+    const unsigned ring_cur = lds_pieces + so, ring_prev = lds_pieces + (unsigned)(((kt + NS - 1) % NS) * STAGE);
     if constexpr (NG == 4) {
       MMF_G6_SUBSTEP(0, 1, 1);
       MMF_G6_SUBSTEP(1, 0, 2);
@@ -416,40 +461,42 @@ __device__ __forceinline__ void gemm6_body(const GemmArgs& args, const int total
     } else {
       MMF_G6_SUBSTEP(0, 1, 1);
     }
-    // last substep: four MFMAs, the stage hand-over, then the rest — MFMAs 4..11 each followed by one read of stage kt + 1's first
-    // fragments, MFMAs 8..15 by this wave's LDS-DMA pieces of stage kt + NS
+    // last substep: four MFMAs, the stage hand-over, then the rest: MFMAs 4..11 each followed by one read of stage kt + 1's first
+    // fragments, MFMAs 12..15 by the late pieces
     const unsigned sn = (unsigned)(((kt + 1) % NS) * STAGE);
 #pragma unroll
     for (int i = 0; i < 4; ++i) mf(fa[1], fb[1], i);
     if constexpr (NEXT) {
-      if constexpr (DMA) {
-        vm_wait<PPW * (NS - 2)>();                           // steady state: the NS - 2 younger stages stay in flight
-      } else {                                               // ring running dry: exactly the stages issued after kt + 1
-        if (ahead >= 3) vm_wait<PPW * 3>(); else if (ahead == 2) vm_wait<PPW * 2>(); else if (ahead == 1) vm_wait<PPW>(); else vm_wait<0>();
+      if constexpr (!(MMF_G6_DBG & 2)) {
+        if constexpr (STEADY) {
+          vm_wait<PPW * (NS - 2)>();                           // the NS - 2 younger stages stay in flight
+        } else {                                               // ring running dry: exactly the stages issued after kt + 1
+          if (ahead >= 3) vm_wait<PPW * 3>(); else if (ahead == 2) vm_wait<PPW * 2>(); else if (ahead == 1) vm_wait<PPW>(); else vm_wait<0>();
+        }
+        __builtin_amdgcn_s_barrier();                          // stage kt + 1 landed for everyone; nobody reads stage kt any more
       }
-      __builtin_amdgcn_s_barrier();                          // stage kt + 1 landed for everyone; nobody reads stage kt any more
+      advance(dA, kstepA * 2);                                 // the descriptors now address stage kt + NS
+      advance(dB, kstepB * 2);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 4; i < 16; ++i) {
       mf(fa[1], fb[1], i);
-      if constexpr (NEXT) { if (i < 12) MMF_G6_READ(fa[0], fb[0], 0, i - 4, sn); }
-      if constexpr (DMA) {
-        if (i >= 8) {
-#pragma unroll
-          for (int q = (i - 8) * PPW / 8; q < (i - 7) * PPW / 8; ++q) issue_piece(kt + NS, q);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
+      if constexpr (NEXT && !(MMF_G6_DBG & 4)) { if (i < 12) MMF_G6_READ(fa[0], fb[0], 0, i - 4, sn); }
+      if (i == 12 && !(MMF_G6_DBG & 1)) { if (late) hot_piece(std::integral_constant<int, 0>{}, ring_cur); }
+      if (i == 13 && !(MMF_G6_DBG & 1)) { if (late) hot_piece(std::integral_constant<int, 1>{}, ring_cur); }
+      if (i == 14 && !(MMF_G6_DBG & 1)) { if (late) hot_piece(std::integral_constant<int, 2>{}, ring_cur); }
+      if (i == 15 && !(MMF_G6_DBG & 1)) { if (late) hot_piece(std::integral_constant<int, 3>{}, ring_cur); }
     }
-    if constexpr (NEXT) frag_wait(fa[0], fb[0]);
+    if constexpr (NEXT && !(MMF_G6_DBG & 4)) frag_wait(fa[0], fb[0]);
   };
-  using T = std::true_type;
-  using F = std::false_type;
-  int kt = 0;
-  for (; kt + NS < KT; ++kt) stage(T{}, T{}, kt, NS - 2);
-  for (; kt + 1 < KT; ++kt) stage(T{}, F{}, kt, min(NS - 2, KT - 2 - kt));
-  stage(F{}, F{}, kt, 0);
+  {
+    int kt = 0;
+    if (KT > 1) { stage(T{}, F{}, 0, min(NS - 2, KT - 2), false, NS < KT); kt = 1; }
+    for (; kt + NS < KT; ++kt) stage(T{}, T{}, kt, NS - 2, true, true);
+    for (; kt + 1 < KT; ++kt) stage(T{}, F{}, kt, min(NS - 2, KT - 2 - kt), kt - 1 + NS < KT, kt + NS < KT);
+    stage(F{}, F{}, kt, 0, false, false);
+  }
 #undef MMF_G6_SUBSTEP
 #undef MMF_G6_READ
 
@@ -459,7 +506,7 @@ __device__ __forceinline__ void gemm6_body(const GemmArgs& args, const int total
 #pragma unroll
       for (int tm = 0; tm < 4; ++tm) {
         const int m = m0 + 128 * wm + 32 * tm + lane;
-        if (m < M) atomicAdd(const_cast<float*>(P.bias) + m, csum[tm]);
+        if ((tm >> 1) == wn && m < M) atomicAdd(const_cast<float*>(P.bias) + m, csum[tm]);
       }
     }
   }
@@ -517,10 +564,23 @@ int mmf_gemm6_launch(const mmf_gemm_problem* problems, int num_problems, int lay
     a.p[i] = p;
   }
   a.tile_start[num_problems] = total;
+  static const int cfg = [] { const char* e = getenv("MMF_GEMM6_CFG"); return e ? atoi(e) : 0; }();   // 0: 32 x 4 stages, 1: 32 x 5, 2: 64 x 2
+  bool k64 = true;
+  for (int i = 0; i < num_problems; ++i) k64 = k64 && (problems[i].K % 64 == 0 || layout == MMF_GEMM_TN);
+  const int c = (cfg == 2 && !k64) ? 0 : cfg;
   switch (layout) {
-    case MMF_GEMM_NT: launch<false, false, 32, 4>(a, total, out_f32, s); break;
-    case MMF_GEMM_NN: launch<false, true, 32, 4>(a, total, out_f32, s); break;
-    default:          launch<true, true, 32, 4>(a, total, out_f32, s); break;
+    case MMF_GEMM_NT:
+      if (c == 1) launch<false, false, 32, 5>(a, total, out_f32, s); else if (c == 2) launch<false, false, 64, 2>(a, total, out_f32, s);
+      else launch<false, false, 32, 4>(a, total, out_f32, s);
+      break;
+    case MMF_GEMM_NN:
+      if (c == 1) launch<false, true, 32, 5>(a, total, out_f32, s); else if (c == 2) launch<false, true, 64, 2>(a, total, out_f32, s);
+      else launch<false, true, 32, 4>(a, total, out_f32, s);
+      break;
+    default:
+      if (c == 1) launch<true, true, 32, 5>(a, total, out_f32, s); else if (c == 2) launch<true, true, 64, 2>(a, total, out_f32, s);
+      else launch<true, true, 32, 4>(a, total, out_f32, s);
+      break;
   }
   MMF_CHECK_LAUNCH("mmf_gemm_grouped(v6)");
   return MMF_OK;

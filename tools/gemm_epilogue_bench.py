@@ -5,7 +5,7 @@ from mmfusion import lib
 from mmfusion.lib import GEMM_NT
 from gemm_bench import bench
 L = lib.load()
-for impl in (4,):
+for impl in (4, 6):
     lib.check(L.mmf_gemm_select_impl(impl))
     for (M, N, K) in [(1024, 1024, 64), (2048, 2048, 64), (4096, 4096, 64), (8192, 3072, 64), (8192, 3072, 128), (8192, 3072, 768), (2048, 2048, 768), (1024, 1024, 768)]:
         us, tf = bench(GEMM_NT, [(M, N, K)], reps=20)
