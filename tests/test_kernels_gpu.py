@@ -121,7 +121,8 @@ def test_gemm_grouped_and_strided():
     assert float(out[:, 264:].float().abs().max()) == 0.0 and float(out[100:, 64:264].float().abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("layout,impl", [(GEMM_TN, 2), (GEMM_TN, 5), (GEMM_NT, 2), (GEMM_NT, 4), (GEMM_NT, 5), (GEMM_NN, 2), (GEMM_NN, 4), (GEMM_NN, 5)])
+@pytest.mark.parametrize("layout,impl", [(GEMM_TN, 2), (GEMM_TN, 5), (GEMM_TN, 6), (GEMM_NT, 2), (GEMM_NT, 4), (GEMM_NT, 5), (GEMM_NT, 6),
+                                         (GEMM_NN, 2), (GEMM_NN, 4), (GEMM_NN, 5), (GEMM_NN, 6)])
 def test_gemm_grouped_many_tiles_mixed_k(layout, impl):
     """A grouped launch big enough for the granule tile -> XCD map (mmf_xcd_tile: >= 8 x 32 tiles handed out in
     32-tile granules, the remainder as one range per XCD) with the maximum problem count and K from 16 to 2048, as in
@@ -129,6 +130,8 @@ def test_gemm_grouped_many_tiles_mixed_k(layout, impl):
     handed out twice with different neighbours, shows up; checked against an fp32 matmul of the same bf16 operands."""
     L = lib.load()
     shapes, ks = [(768, 768), (256, 384), (1536, 768), (520, 200)], [1000, 480, 16, 2048, 64]
+    if impl == 6 and layout != GEMM_TN:      # the one-wave-per-SIMD kernel takes NT / NN reductions in whole 32-column stages
+        ks = [1024, 480, 32, 2048, 64]
     probs, refs = [], []
     for i in range(lib.GEMM_MAX_PROBLEMS):
         (M, N), K = shapes[i % len(shapes)], ks[i % len(ks)]
@@ -148,6 +151,60 @@ def test_gemm_grouped_many_tiles_mixed_k(layout, impl):
     for i, ((_, _, C, _, _), ref) in enumerate(zip(probs, refs)):
         assert not bool(torch.isnan(C).any()), f"problem {i}: unwritten output tile"
         assert rel(C, ref) < 1e-5, f"problem {i}: {rel(C, ref):.3e}"
+
+
+    if impl == 6:
+        assert L.mmf_gemm_last_impl() == 6
+
+
+def test_gemm6_epilogues_and_edge_tiles():
+    """The one-wave-per-SIMD kernel (gemm6.hip) pinned explicitly: every bf16 epilogue form on ragged NT / NN problems
+    (tiles that hang over M and N), and f32 accumulate."""
+    L = lib.load()
+    lib.check(L.mmf_gemm_select_impl(6))
+    try:
+        for (M, N, K) in [(1000, 264, 3072), (300, 520, 96), (257, 8, 32)]:
+            A, B_, bias, aux = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3), rnd(M, N, seed=4)
+            a16, b16, aux16 = bf(A), bf(B_), bf(aux)
+            ref = a16.float().cpu() @ b16.float().cpu().t()
+            C16 = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+            ops.gemm(GEMM_NT, a16, b16, C16, bias=bias.to(DEV), epilogue=EPI_BIAS | EPI_RELU)
+            assert L.mmf_gemm_last_impl() == 6
+            assert rel(C16, torch.relu(ref + bias)) < 2 ** -8
+            ops.gemm(GEMM_NT, a16, b16, C16, bias=bias.to(DEV), aux=aux16, epilogue=EPI_BIAS | EPI_ADD_AUX)
+            assert rel(C16, ref + bias + aux16.float().cpu()) < 2 ** -8
+            ops.gemm(GEMM_NT, a16, b16, C16, aux=aux16, epilogue=EPI_MASK_AUX)
+            assert rel(C16, ref * (aux16.float().cpu() > 0)) < 2 ** -8
+            C = torch.full((M, N), 1.0, device=DEV)
+            ops.gemm(GEMM_NT, a16, b16, C, epilogue=EPI_ACCUM)
+            assert L.mmf_gemm_last_impl() == 6 and rel(C, ref + 1.0) < 1e-5
+            bn = bf(rnd(K, N, seed=5, scale=K ** -0.5))                       # NN: dx = dy . W
+            ops.gemm(GEMM_NN, a16, bn, C16, aux=aux16, epilogue=EPI_ADD_AUX)
+            assert L.mmf_gemm_last_impl() == 6
+            assert rel(C16, a16.float().cpu() @ bn.float().cpu() + aux16.float().cpu()) < 2 ** -8
+    finally:
+        lib.check(L.mmf_gemm_select_impl(0))
+
+
+def test_gemm6_wgrad_reads_nothing_it_should_not_use():
+    """wgrad operands as the LAST column blocks of packed buffers whose other columns are NaN, with M and N that leave
+    edge tiles: the tile is fetched without a column predicate, so NaNs from beyond the valid columns sit in LDS — they
+    must reach neither the weight gradient nor (through the selector rows of the bias-gradient MFMA) the bias gradient,
+    and nothing past the last valid element may be read (the buffer ranges end there)."""
+    L = lib.load()
+    K, M, N = 515, 200, 328
+    pa = torch.full((K, 3 * M), float("nan"), dtype=torch.bfloat16, device=DEV)
+    pb = torch.full((K, 2 * N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    A, B_ = rnd(K, M, seed=7), rnd(K, N, seed=8, scale=K ** -0.5)
+    pa[:, 2 * M:] = bf(A)
+    pb[:, N:] = bf(B_)
+    a16, b16 = pa[:, 2 * M:], pb[:, N:]
+    C = torch.full((M, N), float("nan"), device=DEV)
+    db = torch.full((M,), 2.0, device=DEV)
+    ops.gemm(GEMM_TN, a16, b16, C, bias=db, epilogue=EPI_COLSUM_A)
+    assert L.mmf_gemm_last_impl() == 6
+    assert rel(C, a16.float().cpu().t() @ b16.float().cpu()) < 1e-5
+    assert rel(db, a16.float().cpu().sum(0) + 2.0) < 1e-5
 
 
 def test_linear_group_on_split3_returns_one_gradient_buffer():
