@@ -22,7 +22,7 @@
 #include <type_traits>
 
 // MMF_G6_DBG (build-time ablation bits, timing only, results wrong): 1 no LDS-DMA in the loop, 2 no stage hand-over (vmcnt +
-// barrier), 4 no fragment reads in the loop
+// barrier), 4 no fragment reads in the loop, 16 three s_nop in place of every piece, 32 every refill fetches the same stage
 #ifndef MMF_G6_DBG
 #define MMF_G6_DBG 0
 #endif
@@ -339,6 +339,11 @@ __device__ __forceinline__ void gemm6_body(const GemmArgs& args, const int total
   const unsigned lds_pieces = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)my_pieces;
   auto hot_piece = [&](auto ic, const unsigned ring_base) {   // piece I of this wave into the ring slot at LDS address ring_base (+ wave)
     constexpr int I = decltype(ic)::value, OFF = I < PPO ? I * 4096 : TILE + (I - PPO) * 4096;
+    if constexpr (MMF_G6_DBG & 16) {                           // ablation: the piece's three issue slots without the piece
+      asm volatile("s_nop 0\n\ts_nop 0\n\ts_nop 0" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      return;
+    }
     if (I < PPO) asm volatile("s_add_i32 m0, %0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(ring_base), "v"(voff[I]), "s"(dA), "n"(OFF) : "memory");
     else         asm volatile("s_add_i32 m0, %0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(ring_base), "v"(voff[I]), "s"(dB), "n"(OFF) : "memory");
     __builtin_amdgcn_sched_barrier(0);
@@ -475,8 +480,10 @@ __device__ __forceinline__ void gemm6_body(const GemmArgs& args, const int total
         }
         __builtin_amdgcn_s_barrier();                          // stage kt + 1 landed for everyone; nobody reads stage kt any more
       }
-      advance(dA, kstepA * 2);                                 // the descriptors now address stage kt + NS
-      advance(dB, kstepB * 2);
+      if constexpr (!(MMF_G6_DBG & 32)) {                      // (ablation 32: the ring is refilled from the same L2-resident stage)
+        advance(dA, kstepA * 2);                               // the descriptors now address stage kt + NS
+        advance(dB, kstepB * 2);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
