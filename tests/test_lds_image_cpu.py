@@ -24,3 +24,14 @@ def test_dma_fill_map_inverts_img_off():
 def test_tr_lane_parts_match_img_off():
     for DH in (96, 64):
         assert chk.tr_parts_ok(DH)
+
+
+def test_gemm6_images_reads_and_piece_maps():
+    """gemm6.hip uses the same image for its GEMM operand tiles: [256][BK] row-read tiles, [BK][256] transposed-read tiles in the
+    standard MFMA k order; the lane parts / immediates of the kernel reproduce img_off, both reads sit on their conflict-free
+    floor, and the 1-KiB LDS-DMA pieces cover each tile exactly once at the image's addresses."""
+    for BK in (32, 64):
+        assert chk.gemm6_row_read_cycles(BK) == 4
+        ok, cyc = chk.gemm6_tr_read_ok(BK // 16)
+        assert ok and cyc == 2
+        assert chk.gemm6_piece_map_ok(False, BK) and chk.gemm6_piece_map_ok(True, BK)
