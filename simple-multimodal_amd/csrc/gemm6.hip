@@ -6,8 +6,9 @@
 // ~60 B/clk, so the burst blocks all eight instruction streams for ~800-1,000 cycles), then every wave reads fragments, then the
 // two waves of a SIMD take turns on the matrix pipe — the CU's three resources are used one after the other.  Here
 //   * a wave owns its SIMD: nothing it does can be covered by a partner, so its stream is software-pipelined by hand: the
-//     fragments of k-substep g+1 are requested before the MFMAs of substep g, the LDS-DMA pieces of a later stage go out one per
-//     MFMA, and the stage hand-over (counted vmcnt, one s_barrier) sits in the middle of the last substep's MFMAs;
+//     fragments of k-substep g+1 are requested one behind each of the first MFMAs of substep g, the LDS-DMA pieces of a later stage
+//     go out behind MFMAs that carry no read, and the stage hand-over (counted vmcnt, one s_barrier) sits inside the last substep's
+//     MFMAs (measured: free there);
 //   * the 128 x 128 wave tile needs 8 fragments per 16 MFMAs (the 128 x 64 tile of gemm4: 12; gemm2's 64 x 64: 16) — a third
 //     fewer LDS bytes per MFMA;
 //   * every fragment read is inline asm (ds_read_b128 / ds_read_b64_tr_b16) behind counted lgkmcnt waits tied to the destination
