@@ -46,10 +46,11 @@ static const int g_shortk_nn = [] { const char* e = getenv("MMF_GEMM_SHORTK_NN")
 // (profiles/r02_gemm_generations.txt: every MulT launch group x {256x128, 256x256, 256x128/32-deep} in isolation).
 static const int g_tn5 = [] { const char* e = getenv("MMF_GEMM_TN5"); return e ? atoi(e) : 0; }();   // wgrad on the 32-deep two-workgroups-per-CU kernel
 static const int g_tn6 = [] { const char* e = getenv("MMF_GEMM_TN6"); return e ? atoi(e) : 1; }();    // wgrad on the one-wave-per-SIMD kernel (round 3 default; 0: the 256x128 ring)
-static const int g_longk6 = [] { const char* e = getenv("MMF_GEMM_LONGK6"); return e ? atoi(e) : 0; }();
+static const int g_g6_maxtiles = [] { const char* e = getenv("MMF_GEMM6_MAXTILES"); return e ? atoi(e) : 1 << 30; }();
+static const int g_longk6 = [] { const char* e = getenv("MMF_GEMM_LONGK6"); return e ? atoi(e) : 512; }();   // round 3 default: every K >= 512 launch
 static const int g_policy = [] { const char* e = getenv("MMF_GEMM_POLICY"); return e ? atoi(e) : 2; }();
-static int auto_impl(const mmf_gemm_problem* p, int n, int layout) {
-  if (layout == MMF_GEMM_TN) return g_tn5 ? 5 : (g_tn6 && mmf_gemm6_supports(p, n, layout)) ? 6 : 2;
+static int auto_impl(const mmf_gemm_problem* p, int n, int layout, bool allow6 = true) {
+  if (layout == MMF_GEMM_TN) return g_tn5 ? 5 : (allow6 && g_tn6 && mmf_gemm6_supports(p, n, layout)) ? 6 : 2;
   long tiles = 0;
   int kmax = 0, kmin = 1 << 30;
   for (int i = 0; i < n; ++i) {
@@ -57,9 +58,10 @@ static int auto_impl(const mmf_gemm_problem* p, int n, int layout) {
     kmax = p[i].K > kmax ? p[i].K : kmax;
     kmin = p[i].K < kmin ? p[i].K : kmin;
   }
-  // long reductions (FFN2, dX: K = 3072): the one-wave-per-SIMD kernel's per-tile overhead (~8 us against ~3.6) is amortised and its
-  // k-loop is the faster one (MMF_GEMM_LONGK6: minimum K, 0 = never)
-  if (g_longk6 > 0 && kmin >= g_longk6 && mmf_gemm6_supports(p, n, layout)) return 6;
+  // The one-wave-per-SIMD kernel (gemm6.hip) for every NT / NN launch whose shortest reduction is at least MMF_GEMM_LONGK6 (default
+  // 512; 0 = never): with its flag-specialised epilogues it is level with or ahead of the ring kernels on every MulT launch group
+  // (profiles/r03_gemm_generations.txt) and worth 2.20 -> 2.12 ms in the step
+  if (allow6 && g_longk6 > 0 && kmin >= g_longk6 && tiles <= g_g6_maxtiles && mmf_gemm6_supports(p, n, layout)) return 6;
   static const int cus = [] { int c = mmf_device_cu_count(); return c > 0 ? c : 256; }();
   const long rounds = (tiles + cus - 1) / cus;
   if (g_policy >= 2) {
@@ -118,7 +120,8 @@ extern "C" int mmf_gemm_grouped_ex(const mmf_gemm_problem* problems, int num_pro
   }
   int impl = gemm_impl();
   if (impl == 0) impl = auto_impl(problems, num_problems, layout);
-  if (impl == 6 && !(mmf_gemm6_supports(problems, num_problems, layout) && mmf_gemm6_supports_epi(epilogue, out_f32))) impl = auto_impl(problems, num_problems, layout);
+  if (impl == 6 && !(mmf_gemm6_supports(problems, num_problems, layout) && mmf_gemm6_supports_epi(epilogue, out_f32)))
+    impl = auto_impl(problems, num_problems, layout, false);
   t_last_impl = impl;
   for (int i = 0; i < num_problems; ++i) {
     const mmf_gemm_problem& p = problems[i];

@@ -151,16 +151,20 @@ __device__ __forceinline__ void tile_origin(const mmf_gemm_problem& P, const int
 // to C: the first form of this epilogue (gemm4's: bias / aux / old-C loads next to each use) spent ~35 us per tile in 64 exposed
 // round trips.  Everything it reads is therefore requested up front: the bias once, and per 32-row block tm the aux row pieces /
 // old C values of block tm + 1 before block tm is finished and stored.
-template <bool OUT_F32>
-__device__ __forceinline__ void tile_epilogue(const GemmArgs& args, const mmf_gemm_problem& P, const int pi, const int mb, const int nb,
-                                              f32x16_t (&acc)[4][4], const int lane) {
+// CT: the epilogue flags as a compile-time mask (alpha = 1, no dropout), or -1: every flag tested at run time.  One wave per SIMD
+// walks the 64 register groups alone: with the flags tested per group the epilogue of a 256 x 256 tile took 10.7 us (ablation
+// -DMMF_G6_DBG=64), ~4 of which are the CU's store path; the step's flag sets are instantiated (tile_epilogue below).
+template <bool OUT_F32, int CT>
+__device__ __forceinline__ void tile_epilogue_mode(const GemmArgs& args, const mmf_gemm_problem& P, const int pi, const int mb, const int nb,
+                                                   f32x16_t (&acc)[4][4], const int lane) {
+  constexpr int MODE = CT < 0 ? 3 : 0;                     // 3: run-time flags
   const int M = P.M, N = P.N;
-  const int epi = args.epi;
+  const int epi = CT < 0 ? args.epi : (CT | (args.epi & MMF_EPI_ACCUM));
   const unsigned short* __restrict__ aux = static_cast<const unsigned short*>(P.aux);
-  const bool do_drop = epi & MMF_EPI_DROPOUT;
+  const bool do_drop = MODE == 3 && (epi & MMF_EPI_DROPOUT);
   const unsigned drop_key = do_drop ? mmf_rng_key(*args.rng_state, args.site, (unsigned)pi) : 0u;
   const float drop_scale = do_drop ? 1.f / (1.f - (float)args.drop_thresh * (1.f / 4294967296.f)) : 1.f;
-  const float alpha = args.alpha;
+  const float alpha = MODE == 3 ? args.alpha : 1.f;
   const bool use_aux = epi & (MMF_EPI_MASK_AUX | MMF_EPI_ADD_AUX);
   const bool use_old = OUT_F32 && (epi & MMF_EPI_ACCUM);
   const int h = lane >> 5;
@@ -175,6 +179,23 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& args, const mmf_ge
       if ((epi & MMF_EPI_BIAS) && ncol(tn, g) < N) bv[tn][g] = *reinterpret_cast<const f32x4_t*>(P.bias + ncol(tn, g));
     }
   auto finish = [&](f32x4_t v, const f32x4_t& b, const u32x2_t& a, int m, int n) -> f32x4_t {  // bias -> relu -> dropout -> mask -> alpha -> residual
+    if constexpr (CT >= 0) {                                // compile-time flag set: bias -> relu -> mask -> residual
+      if constexpr (CT & MMF_EPI_BIAS) v += b;
+      if constexpr (CT & MMF_EPI_RELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+      }
+      if constexpr (CT & (MMF_EPI_MASK_AUX | MMF_EPI_ADD_AUX)) {
+        const float a0 = bf16lo(a[0]), a1 = bf16hi(a[0]), a2 = bf16lo(a[1]), a3 = bf16hi(a[1]);
+        if constexpr (CT & MMF_EPI_MASK_AUX) {
+          v[0] = a0 > 0.f ? v[0] : 0.f; v[1] = a1 > 0.f ? v[1] : 0.f;
+          v[2] = a2 > 0.f ? v[2] : 0.f; v[3] = a3 > 0.f ? v[3] : 0.f;
+        } else {
+          v[0] += a0; v[1] += a1; v[2] += a2; v[3] += a3;
+        }
+      }
+      return v;
+    }
     v += b;
     if (epi & MMF_EPI_RELU) {
 #pragma unroll
@@ -268,6 +289,22 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& args, const mmf_ge
       }
     }
   }
+}
+
+template <bool OUT_F32>
+__device__ __forceinline__ void tile_epilogue(const GemmArgs& args, const mmf_gemm_problem& P, const int pi, const int mb, const int nb,
+                                              f32x16_t (&acc)[4][4], const int lane) {
+  const int e = args.epi & ~(MMF_EPI_ACCUM | MMF_EPI_COLSUM_A);
+  const bool unit = args.alpha == 1.f;
+  // the flag sets of the fusion step: dgrads / wgrad (none), in-projections (bias), FFN1 (bias + ReLU), out-projection and FFN2
+  // (bias + residual), dH (ReLU mask), dX (residual gradient)
+  if (e == 0 && unit)                                              tile_epilogue_mode<OUT_F32, 0>(args, P, pi, mb, nb, acc, lane);
+  else if (e == MMF_EPI_BIAS && unit)                              tile_epilogue_mode<OUT_F32, MMF_EPI_BIAS>(args, P, pi, mb, nb, acc, lane);
+  else if (e == (MMF_EPI_BIAS | MMF_EPI_RELU) && unit)             tile_epilogue_mode<OUT_F32, MMF_EPI_BIAS | MMF_EPI_RELU>(args, P, pi, mb, nb, acc, lane);
+  else if (!OUT_F32 && e == (MMF_EPI_BIAS | MMF_EPI_ADD_AUX) && unit) tile_epilogue_mode<OUT_F32, MMF_EPI_BIAS | MMF_EPI_ADD_AUX>(args, P, pi, mb, nb, acc, lane);
+  else if (!OUT_F32 && e == MMF_EPI_MASK_AUX && unit)              tile_epilogue_mode<OUT_F32, MMF_EPI_MASK_AUX>(args, P, pi, mb, nb, acc, lane);
+  else if (!OUT_F32 && e == MMF_EPI_ADD_AUX && unit)               tile_epilogue_mode<OUT_F32, MMF_EPI_ADD_AUX>(args, P, pi, mb, nb, acc, lane);
+  else                                                             tile_epilogue_mode<OUT_F32, -1>(args, P, pi, mb, nb, acc, lane);
 }
 
 // the whole kernel as a device function (the __global__ wrapper below only owns the LDS): with the inline-asm reads reachable
