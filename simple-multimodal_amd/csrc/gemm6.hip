@@ -399,13 +399,9 @@ __device__ __forceinline__ void gemm6_body(const GemmArgs& args, const int total
   la0 += smem_base + qa; la1 += smem_base + qa;
   lb0 += smem_base + TILE + qb; lb1 += smem_base + TILE + qb;
 
-  f32x16_t acc[4][4];                                         // [tn][tm]
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  // [tn][tm]; never zeroed: the tile's first sixteen MFMAs take a zero constant as their C operand (256 v_accvgpr_write = 0.5 us per
+  // tile for a wave that owns its SIMD)
+  f32x16_t acc[4][4];
   // the tile column n0 == 0 carries the bias gradient; its four waves share the extra MFMAs: wave (wm, wn) sums blocks 2 wn, 2 wn + 1 of
   // its 128 m-columns (two extra MFMAs per substep in every wave instead of four in two of them: the tile's barrier waits for the slowest)
   const bool do_colsum = A_KR && (args.epi & MMF_EPI_COLSUM_A) && n0 == 0;
@@ -444,9 +440,10 @@ __device__ __forceinline__ void gemm6_body(const GemmArgs& args, const int total
   frag_wait(fa[0], fb[0]);
 
   // MFMA i of a substep, (tm, tn) = (i / 4, i % 4); the bias-gradient MFMA rides behind each row's last
-  auto mf = [&](const Frag4<A_KR>& a, const Frag4<B_KR>& b, int i) {
+  auto mf = [&](const Frag4<A_KR>& a, const Frag4<B_KR>& b, int i, bool first = false) {
     const int tm = i >> 2, tn = i & 3;
-    acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b.get(tn), a.get(tm), acc[tn][tm], 0, 0, 0);
+    const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b.get(tn), a.get(tm), first ? zero : acc[tn][tm], 0, 0, 0);
     if (A_KR && do_colsum && tn == 3 && (tm >> 1) == wn) {
       u32x4_t fm = __builtin_bit_cast(u32x4_t, a.get(tm));
       // columns past M hold whatever lies behind the row in memory; with the selector a NaN there would reach the valid
@@ -478,7 +475,7 @@ __device__ __forceinline__ void gemm6_body(const GemmArgs& args, const int total
 #define MMF_G6_SUBSTEP(cur, nxt, G)                                                                    \
   do {                                                                                                 \
     _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                                   \
-      mf(fa[cur], fb[cur], i);                                                                         \
+      mf(fa[cur], fb[cur], i, FIRST && (G) == 1);                                                      \
       if (i < 8 && !(MMF_G6_DBG & 4)) MMF_G6_READ(fa[nxt], fb[nxt], G, i, so);                        \
       if (i == 8 && !(MMF_G6_DBG & 1)) { if (early) hot_piece(std::integral_constant<int, 4 * (G)>{}, ring_prev); }      \
       if (i == 10 && !(MMF_G6_DBG & 1)) { if (early) hot_piece(std::integral_constant<int, 4 * (G) + 1>{}, ring_prev); } \
@@ -493,8 +490,8 @@ __device__ __forceinline__ void gemm6_body(const GemmArgs& args, const int total
   // One stage.  NEXT: stage kt + 1 exists (hand-over + its first fragments).  STEADY: both refills (stage kt - 1 + NS early,
   // stage kt + NS late) exist and no condition is evaluated — a uniform branch costs a wave that owns its SIMD 10-20 idle
   // matrix-pipe cycles; the few stages at the ends of the sweep take the checked form.
-  auto stage = [&](auto next_c, auto steady_c, const int kt, const int ahead, const bool e, const bool l) {
-    constexpr bool NEXT = decltype(next_c)::value, STEADY = decltype(steady_c)::value;
+  auto stage = [&](auto next_c, auto steady_c, auto first_c, const int kt, const int ahead, const bool e, const bool l) {
+    constexpr bool NEXT = decltype(next_c)::value, STEADY = decltype(steady_c)::value, FIRST = decltype(first_c)::value;
     const bool early = STEADY || e, late = STEADY || l;
     const unsigned so = (unsigned)((kt % NS) * STAGE);
     const unsigned ring_cur = lds_pieces + so, ring_prev = lds_pieces + (unsigned)(((kt + NS - 1) % NS) * STAGE);
@@ -538,10 +535,14 @@ __device__ __forceinline__ void gemm6_body(const GemmArgs& args, const int total
   };
   {
     int kt = 0;
-    if (KT > 1) { stage(T{}, F{}, 0, min(NS - 2, KT - 2), false, NS < KT); kt = 1; }
-    for (; kt + NS < KT; ++kt) stage(T{}, T{}, kt, NS - 2, true, true);
-    for (; kt + 1 < KT; ++kt) stage(T{}, F{}, kt, min(NS - 2, KT - 2 - kt), kt - 1 + NS < KT, kt + NS < KT);
-    stage(F{}, F{}, kt, 0, false, false);
+    if (KT > 1) {
+      stage(T{}, F{}, T{}, 0, min(NS - 2, KT - 2), false, NS < KT);
+      for (kt = 1; kt + NS < KT; ++kt) stage(T{}, T{}, F{}, kt, NS - 2, true, true);
+      for (; kt + 1 < KT; ++kt) stage(T{}, F{}, F{}, kt, min(NS - 2, KT - 2 - kt), kt - 1 + NS < KT, kt + NS < KT);
+      stage(F{}, F{}, F{}, kt, 0, false, false);
+    } else {
+      stage(F{}, F{}, T{}, 0, 0, false, false);
+    }
   }
 #undef MMF_G6_SUBSTEP
 #undef MMF_G6_READ
