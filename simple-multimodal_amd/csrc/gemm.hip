@@ -50,7 +50,15 @@ static const int g_g6_maxtiles = [] { const char* e = getenv("MMF_GEMM6_MAXTILES
 static const int g_longk6 = [] { const char* e = getenv("MMF_GEMM_LONGK6"); return e ? atoi(e) : 512; }();   // round 3 default: every K >= 512 launch
 static const int g_policy = [] { const char* e = getenv("MMF_GEMM_POLICY"); return e ? atoi(e) : 2; }();
 static int auto_impl(const mmf_gemm_problem* p, int n, int layout, bool allow6 = true) {
-  if (layout == MMF_GEMM_TN) return g_tn5 ? 5 : (allow6 && g_tn6 && mmf_gemm6_supports(p, n, layout)) ? 6 : 2;
+  if (layout == MMF_GEMM_TN) {
+    if (g_tn5) return 5;
+    long t6 = 0;
+    for (int i = 0; i < n; ++i) t6 += (long)((p[i].M + 255) / 256) * ((p[i].N + 255) / 256);
+    static const int cus_tn = [] { int c = mmf_device_cu_count(); return c > 0 ? c : 256; }();
+    // a launch that would leave more than half of the CUs without a 256 x 256 tile (a single layer's weight gradient) keeps the
+    // 256 x 128 ring: twice the tiles
+    return (allow6 && g_tn6 && 2 * t6 >= cus_tn && mmf_gemm6_supports(p, n, layout)) ? 6 : 2;
+  }
   long tiles = 0;
   int kmax = 0, kmin = 1 << 30;
   for (int i = 0; i < n; ++i) {
@@ -60,8 +68,10 @@ static int auto_impl(const mmf_gemm_problem* p, int n, int layout, bool allow6 =
   }
   // The one-wave-per-SIMD kernel (gemm6.hip) for every NT / NN launch whose shortest reduction is at least MMF_GEMM_LONGK6 (default
   // 512; 0 = never): with its flag-specialised epilogues it is level with or ahead of the ring kernels on every MulT launch group
-  // (profiles/r03_gemm_generations.txt) and worth 2.20 -> 2.12 ms in the step
-  if (allow6 && g_longk6 > 0 && kmin >= g_longk6 && tiles <= g_g6_maxtiles && mmf_gemm6_supports(p, n, layout)) return 6;
+  // (profiles/r03_gemm_generations.txt) and worth 2.20 -> 2.12 ms in the step; launches that would leave more than half of the CUs
+  // without a 256 x 256 tile keep round 2's rule (smaller tiles)
+  static const int cus6 = [] { int c = mmf_device_cu_count(); return c > 0 ? c : 256; }();
+  if (allow6 && g_longk6 > 0 && kmin >= g_longk6 && tiles <= g_g6_maxtiles && 2 * tiles >= cus6 && mmf_gemm6_supports(p, n, layout)) return 6;
   static const int cus = [] { int c = mmf_device_cu_count(); return c > 0 ? c : 256; }();
   const long rounds = (tiles + cus - 1) / cus;
   if (g_policy >= 2) {

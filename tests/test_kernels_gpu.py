@@ -201,8 +201,12 @@ def test_gemm6_wgrad_reads_nothing_it_should_not_use():
     a16, b16 = pa[:, 2 * M:], pb[:, N:]
     C = torch.full((M, N), float("nan"), device=DEV)
     db = torch.full((M,), 2.0, device=DEV)
-    ops.gemm(GEMM_TN, a16, b16, C, bias=db, epilogue=EPI_COLSUM_A)
-    assert L.mmf_gemm_last_impl() == 6
+    lib.check(L.mmf_gemm_select_impl(6))            # (two tiles: the automatic rule would take the 256 x 128 ring)
+    try:
+        ops.gemm(GEMM_TN, a16, b16, C, bias=db, epilogue=EPI_COLSUM_A)
+        assert L.mmf_gemm_last_impl() == 6
+    finally:
+        lib.check(L.mmf_gemm_select_impl(0))
     assert rel(C, a16.float().cpu().t() @ b16.float().cpu()) < 1e-5
     assert rel(db, a16.float().cpu().sum(0) + 2.0) < 1e-5
 
