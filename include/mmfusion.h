@@ -107,7 +107,8 @@ int mmf_gemm_grouped_ex(const mmf_gemm_problem* problems, int num_problems, int 
 /* Tuning hook: which kernel mmf_gemm_grouped dispatches to (0 automatic [default]; 2 LDS-DMA ring 256x128; 4 LDS-DMA ring
  * 256x256; 5 256x128 with a 32-deep k-step and two workgroups per CU; 6 256x256 on one wave per SIMD with 128x128 wave tiles
  * [gemm6.hip: any K for TN, K % 32 == 0 for NT / NN, no aux epilogue with f32 output — otherwise the automatic choice]).
- * Automatic: TN (wgrad) -> 6, NT / NN per launch from the tile count and K (gemm.hip auto_impl).  1 and 3 (rounds 1-2: register-staged 128x128, persistent ring) were
+ * Automatic: 6 for TN (wgrad) and for NT / NN launches with K >= 512 that give at least half of the CUs a tile, else per launch
+ * from the tile count and K (gemm.hip auto_impl).  1 and 3 (rounds 1-2: register-staged 128x128, persistent ring) were
  * removed in round 3 and are refused with MMF_E_SHAPE.  Results are identical up to f32 summation order; exists so that A/B
  * timings can be interleaved inside one process. */
 int mmf_gemm_select_impl(int impl);
