@@ -328,22 +328,31 @@ class MultimodalTransformer(_FusionBase):
             return _cross_blocks([blocks[i] for i in g], [qs[i] for i in g], [kvs[i] for i in g], B,
                                  [Tqs[i] for i in g], [Tks[i] for i in g], p, [ress[i] for i in g])
 
-        if streams and _MULT_STREAMS == 2 and _MULT_GROUPING == "modality":
-            # Two independent chains up to the pooled projections: text (blocks 0, 1 -> sum -> text self-attention) on the
-            # current stream, audio + video (blocks 2..5 -> sums -> their self-attentions) on a side stream.  Autograd
-            # replays each node's backward on its forward stream, so the backward is two chains wide as well.
+        if streams and _MULT_STREAMS == 2 and _MULT_GROUPING in ("modality", "tv_a"):
+            # Two independent chains up to the pooled projections, cut by QUERY modality; autograd replays each node's backward
+            # on its forward stream, so the backward is two chains wide as well.  "modality": text on the current stream, audio +
+            # video on the side stream.  "tv_a" (MMF_MULT_GROUPING=tv_a): text + video | audio — tried because the audio + video stream finishes its
+            # backward ~110 us after the text stream (its 30-row attention problems are one-wave chains): level, 2.163 vs 2.165 ms.
+            mods = {"modality": ([0], [1, 2]), "tv_a": ([0, 2], [1])}[_MULT_GROUPING]
+            xs3, Ts3 = [t, a, v], [Tt, Ta, Tv]
+
+            def chain(ms):          # query modalities ms: their two cross blocks each, the three-way sums, the self-attentions
+                outs = run_blocks([2 * m + j for m in ms for j in (0, 1)])
+                es = ops.add3_group([(xs3[m], outs[2 * i], outs[2 * i + 1]) for i, m in enumerate(ms)])   # :156-158
+                return _self_attention_core([mhas[m] for m in ms], es, B, [Ts3[m] for m in ms], p)
             main = torch.cuda.current_stream()
             side = ops.branch_stream(1)                     # stream 0 belongs to HierarchicalFusion's small branches
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                a_t, a_v, v_t, v_a = run_blocks([2, 3, 4, 5])
-                ea, ev = ops.add3_group([(a, a_t, a_v), (v, v_t, v_a)])                    # :157-158
-                att_av = _self_attention_core(mhas[1:], [ea, ev], B, [Ta, Tv], p)
-            t_a, t_v = run_blocks([0, 1])
-            et = ops.add3_group([(t, t_a, t_v)])[0]                                        # :156
-            att = _self_attention_core(mhas[:1], [et], B, [Tt], p) + att_av
+                att_side = chain(mods[1])
+            att_main = chain(mods[0])
+            att = [None, None, None]
+            for m, x in zip(mods[0], att_main):
+                att[m] = x
+            for m, x in zip(mods[1], att_side):
+                att[m] = x
             main.wait_stream(side)
-            for x in att_av:
+            for x in att_side:
                 x.record_stream(main)
         else:
             if streams:
