@@ -108,12 +108,19 @@ int mmf_gemm_grouped_ex(const mmf_gemm_problem* problems, int num_problems, int 
  * 256x256; 5 256x128 with a 32-deep k-step and two workgroups per CU; 6 256x256 on one wave per SIMD with 128x128 wave tiles
  * [gemm6.hip: any K for TN, K % 32 == 0 for NT / NN, no aux epilogue with f32 output — otherwise the automatic choice]).
  * Automatic: 6 for TN (wgrad) and for NT / NN launches with K >= 512 that give at least half of the CUs a tile, else per launch
- * from the tile count and K (gemm.hip auto_impl).  1 and 3 (rounds 1-2: register-staged 128x128, persistent ring) were
+ * from the tile count and K (gemm.hip auto_impl); 7: see mmf_gemm_set_persistent_workgroups below.  1 and 3 (rounds 1-2: register-staged 128x128, persistent ring) were
  * removed in round 3 and are refused with MMF_E_SHAPE.  Results are identical up to f32 summation order; exists so that A/B
  * timings can be interleaved inside one process. */
 int mmf_gemm_select_impl(int impl);
 /* the kernel generation the calling thread's last mmf_gemm_grouped[_ex] call dispatched to (profiling labels) */
 int mmf_gemm_last_impl(void);
+/* Round 4, generation 7 (gemm7.hip): generation 6's tile on PERSISTENT workgroups — one per CU, each walking the tiles w, w + grid,
+ * ... of the launch with its LDS ring running on across tile boundaries (no ring fill and no idle matrix pipe between tiles).  NT /
+ * NN with bf16 output, K % 32 == 0 and K >= 160; the automatic choice takes it for every such launch generation 6 would get that
+ * has more tiles than CUs (MMF_GEMM_PERSIST=0: off).  Results are bit-identical to generation 6.
+ * mmf_gemm_set_persistent_workgroups(n): grid size of generation 7 (0 = the CU count [default]); a test / tuning hook: with a
+ * small n a small problem exercises many tiles per workgroup. */
+int mmf_gemm_set_persistent_workgroups(int n);
 
 /* ------------------------------------------------------------------------------------------
  * Skinny-M linear layers (1 <= M <= 64 rows): the (B, d) MLPs of the Early / Contrastive / Adaptive /

@@ -24,13 +24,16 @@ int mmf_gemm6_launch(const mmf_gemm_problem* problems, int num_problems, int lay
                      int out_f32, const mmf_gemm_extra* extra, hipStream_t s);   // gemm6.hip: one wave per SIMD, 128x128 wave tiles
 bool mmf_gemm6_supports(const mmf_gemm_problem* problems, int num_problems, int layout);
 bool mmf_gemm6_supports_epi(int epilogue, int out_f32);
+int mmf_gemm7_launch(const mmf_gemm_problem* problems, int num_problems, int layout, int epilogue,
+                     int out_f32, const mmf_gemm_extra* extra, hipStream_t s);   // gemm7.hip: gemm6's tile, persistent workgroups
+bool mmf_gemm7_supports(const mmf_gemm_problem* problems, int num_problems, int layout, int epilogue, int out_f32, const mmf_gemm_extra* extra);
 
 // Implementation switch (A/B runs in one process: tools/gemm_bench.py): 0 = automatic (default), 1 =
 // register-staged 128x128 kernel of this file, 2 = 256x128 LDS-DMA ring (gemm2.hip), 3 = its persistent
 // form (gemm3.hip), 4 = 256x256 LDS-DMA ring (gemm4.hip).  Default from MMF_GEMM_IMPL, else automatic.
 static int g_gemm_impl = [] {
   const char* e = getenv("MMF_GEMM_IMPL");
-  int v = (e && e[0] >= '0' && e[0] <= '6') ? e[0] - '0' : 0;
+  int v = (e && e[0] >= '0' && e[0] <= '7') ? e[0] - '0' : 0;
   if (v == 1 || v == 3) v = 0;
   return v;
 }();
@@ -49,6 +52,10 @@ static const int g_tn6 = [] { const char* e = getenv("MMF_GEMM_TN6"); return e ?
 static const int g_g6_maxtiles = [] { const char* e = getenv("MMF_GEMM6_MAXTILES"); return e ? atoi(e) : 1 << 30; }();
 static const int g_longk6 = [] { const char* e = getenv("MMF_GEMM_LONGK6"); return e ? atoi(e) : 512; }();   // round 3 default: every K >= 512 launch
 static const int g_policy = [] { const char* e = getenv("MMF_GEMM_POLICY"); return e ? atoi(e) : 2; }();
+// round 4: NT / NN launches that gemm6 would take go to its persistent form (gemm7.hip) when the launch has more tiles than
+// MMF_GEMM_PERSIST_MINTILES (default: the CU count, i.e. some workgroup walks at least two tiles); MMF_GEMM_PERSIST=0: off
+static int g_persist = [] { const char* e = getenv("MMF_GEMM_PERSIST"); return e ? atoi(e) : 1; }();
+static const int g_persist_min = [] { const char* e = getenv("MMF_GEMM_PERSIST_MINTILES"); return e ? atoi(e) : -1; }();
 static int auto_impl(const mmf_gemm_problem* p, int n, int layout, bool allow6 = true) {
   if (layout == MMF_GEMM_TN) {
     if (g_tn5) return 5;
@@ -99,7 +106,7 @@ static int gemm_impl() { return g_gemm_impl; }
 static thread_local int t_last_impl = 0;
 extern "C" int mmf_gemm_last_impl(void) { return t_last_impl; }
 extern "C" int mmf_gemm_select_impl(int impl) {
-  if (impl < 0 || impl > 6) MMF_FAIL(MMF_E_UNSUPPORTED, "mmf_gemm_select_impl: %d not in 0..6", impl);
+  if (impl < 0 || impl > 7) MMF_FAIL(MMF_E_UNSUPPORTED, "mmf_gemm_select_impl: %d not in 0..7", impl);
   if (impl == 1 || impl == 3)
     MMF_FAIL(MMF_E_UNSUPPORTED, "mmf_gemm_select_impl: generation %d was removed in round 3 (built: 2, 4, 5, 6)", impl);
   g_gemm_impl = impl;
@@ -132,6 +139,14 @@ extern "C" int mmf_gemm_grouped_ex(const mmf_gemm_problem* problems, int num_pro
   if (impl == 0) impl = auto_impl(problems, num_problems, layout);
   if (impl == 6 && !(mmf_gemm6_supports(problems, num_problems, layout) && mmf_gemm6_supports_epi(epilogue, out_f32)))
     impl = auto_impl(problems, num_problems, layout, false);
+  if (impl == 6 && gemm_impl() == 0 && g_persist && mmf_gemm7_supports(problems, num_problems, layout, epilogue, out_f32, extra)) {
+    long tiles = 0;
+    for (int i = 0; i < num_problems; ++i) tiles += (long)((problems[i].M + 255) / 256) * ((problems[i].N + 255) / 256);
+    static const int cus7 = [] { int c = mmf_device_cu_count(); return c > 0 ? c : 256; }();
+    if (tiles > (g_persist_min >= 0 ? g_persist_min : cus7)) impl = 7;
+  }
+  if (impl == 7 && !mmf_gemm7_supports(problems, num_problems, layout, epilogue, out_f32, extra))
+    impl = mmf_gemm6_supports(problems, num_problems, layout) && mmf_gemm6_supports_epi(epilogue, out_f32) ? 6 : auto_impl(problems, num_problems, layout, false);
   t_last_impl = impl;
   for (int i = 0; i < num_problems; ++i) {
     const mmf_gemm_problem& p = problems[i];
@@ -160,5 +175,6 @@ extern "C" int mmf_gemm_grouped_ex(const mmf_gemm_problem* problems, int num_pro
   if (impl == 4) return mmf_gemm4_launch(problems, num_problems, layout, epilogue, out_f32, extra, s);
   if (impl == 5) return mmf_gemm5_launch(problems, num_problems, layout, epilogue, out_f32, extra, s);
   if (impl == 6) return mmf_gemm6_launch(problems, num_problems, layout, epilogue, out_f32, extra, s);
-  MMF_FAIL(MMF_E_UNSUPPORTED, "mmf_gemm_grouped: kernel generation %d is not built (2, 4, 5, 6)", impl);
+  if (impl == 7) return mmf_gemm7_launch(problems, num_problems, layout, epilogue, out_f32, extra, s);
+  MMF_FAIL(MMF_E_UNSUPPORTED, "mmf_gemm_grouped: kernel generation %d is not built (2, 4, 5, 6, 7)", impl);
 }

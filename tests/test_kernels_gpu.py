@@ -186,6 +186,96 @@ def test_gemm6_epilogues_and_edge_tiles():
         lib.check(L.mmf_gemm_select_impl(0))
 
 
+def _persistent_case(layout, shapes_k, epi, wgs, seed0=0):
+    """one grouped launch on generation 6 and on generation 7 (persistent, `wgs` workgroups): -> (outputs6, outputs7, refs)"""
+    L = lib.load()
+    probs6, probs7, refs = [], [], []
+    for i, (M, N, K, pad) in enumerate(shapes_k):
+        # operands as column slices of wider buffers (pad extra columns): leading dimensions differ between the problems
+        abuf = bf(rnd(M, K + pad, seed=seed0 + 10 * i + 1))
+        a16 = abuf[:, pad:]
+        if layout == GEMM_NT:
+            bbuf = bf(rnd(N, K + 2 * pad, seed=seed0 + 10 * i + 2, scale=K ** -0.5))
+            b16 = bbuf[:, 2 * pad:]
+        else:
+            bbuf = bf(rnd(K, N + 2 * pad, seed=seed0 + 10 * i + 2, scale=K ** -0.5))
+            b16 = bbuf[:, :N]
+        bias = rnd(N, seed=seed0 + 10 * i + 3).to(DEV) if epi & EPI_BIAS else None
+        aux16 = bf(rnd(M, N, seed=seed0 + 10 * i + 4)) if epi & (EPI_ADD_AUX | EPI_MASK_AUX) else None
+        ref = a16.float().cpu() @ (b16.float().cpu().t() if layout == GEMM_NT else b16.float().cpu())
+        if epi & EPI_BIAS:
+            ref = ref + bias.cpu()
+        if epi & EPI_RELU:
+            ref = torch.relu(ref)
+        if epi & EPI_MASK_AUX:
+            ref = ref * (aux16.float().cpu() > 0)
+        if epi & EPI_ADD_AUX:
+            ref = ref + aux16.float().cpu()
+        refs.append(ref)
+        c6 = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+        c7 = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+        probs6.append((a16, b16, c6, bias, aux16))
+        probs7.append((a16, b16, c7, bias, aux16))
+    try:
+        lib.check(L.mmf_gemm_select_impl(6))
+        ops.gemm_group(layout, probs6, epi)
+        assert L.mmf_gemm_last_impl() == 6
+        lib.check(L.mmf_gemm_select_impl(7))
+        lib.check(L.mmf_gemm_set_persistent_workgroups(wgs))
+        ops.gemm_group(layout, probs7, epi)
+        assert L.mmf_gemm_last_impl() == 7
+        torch.cuda.synchronize()
+    finally:
+        lib.check(L.mmf_gemm_select_impl(0))
+        lib.check(L.mmf_gemm_set_persistent_workgroups(0))
+    return [p[2] for p in probs6], [p[2] for p in probs7], refs
+
+
+@pytest.mark.parametrize("layout", [GEMM_NT, GEMM_NN])
+@pytest.mark.parametrize("wgs", [1, 3, 8, 0])
+def test_gemm7_persistent_walks_tiles_bit_identical_to_gemm6(layout, wgs):
+    """The persistent kernel (gemm7.hip): a grouped launch of ragged problems with different K (from the minimum of five stages up)
+    and different leading dimensions, walked by 1 / 3 / 8 / CU-count workgroups — so a workgroup crosses tile AND problem
+    boundaries with its ring running (descriptor and per-lane offset switch, the ring running dry only at its last tile) — must
+    write every output element (NaN pre-fill), match the f32 matmul and equal generation 6 BIT FOR BIT (same MFMA order per tile;
+    with a bias: up to one bf16 ulp on a few elements, see below)."""
+    shapes = [(520, 264, 160, 8), (300, 520, 768, 0), (257, 8, 192, 16), (1000, 392, 512, 8), (256, 256, 2048, 0), (40, 1032, 224, 24)]
+    # the (layout, flag set) pairs generation 7 is instantiated for — the fusion step's: everything else stays on generation 6
+    epis = (0, EPI_BIAS, EPI_BIAS | EPI_RELU, EPI_BIAS | EPI_ADD_AUX) if layout == GEMM_NT else (0, EPI_MASK_AUX, EPI_ADD_AUX)
+    for epi in epis:
+        c6, c7, refs = _persistent_case(layout, shapes, epi, wgs, seed0=100 * epi)
+        for i, (a, b, r) in enumerate(zip(c6, c7, refs)):
+            assert not bool(torch.isnan(b.float()).any()), f"epi {epi} problem {i}: unwritten output"
+            assert rel(b, r) < 2 ** -8, f"epi {epi} problem {i}: {rel(b, r):.3e}"
+            if epi & EPI_BIAS:
+                # generation 7 STARTS its accumulators from the bias (sixteen MFMAs per tile) instead of adding it at the end: the same
+                # real number rounded along a different f32 path — a bf16 output may differ by one ulp on a small fraction of elements
+                d = (a.float() - b.float()).abs()
+                assert float(d.max()) <= 2 ** -7 * max(1.0, float(a.float().abs().max())), f"epi {epi} problem {i}"
+                assert float((d > 0).float().mean()) < 0.02, f"epi {epi} problem {i}: {float((d > 0).float().mean()):.4f} of the elements differ"
+            else:
+                assert torch.equal(a, b), f"epi {epi} problem {i}: generation 7 differs from generation 6"
+
+
+def test_gemm7_is_the_automatic_choice_for_multi_round_launches():
+    """automatic rule: an NT launch with more 256 x 256 tiles than CUs and K >= 512 goes to the persistent kernel, a one-round launch and
+    an f32-output launch stay on generation 6"""
+    L = lib.load()
+    cus = L.mmf_device_cu_count()
+    rows = 256 * (cus // 3 + 1)                                   # x 3 column tiles > CUs
+    a, w = bf(rnd(rows, 512, seed=1)), bf(rnd(768, 512, seed=2, scale=0.05))
+    c = torch.empty((rows, 768), dtype=torch.bfloat16, device=DEV)
+    ops.gemm(GEMM_NT, a, w, c)
+    assert L.mmf_gemm_last_impl() == 7
+    assert rel(c, a.float().cpu() @ w.float().cpu().t()) < 2 ** -8
+    half = rows // 2 // 256 * 256
+    ops.gemm(GEMM_NT, a[:half], w, c[:half])
+    assert L.mmf_gemm_last_impl() == 6
+    cf = torch.empty((rows, 768), device=DEV)
+    ops.gemm(GEMM_NT, a, w, cf)
+    assert L.mmf_gemm_last_impl() == 6
+
+
 def test_gemm6_wgrad_reads_nothing_it_should_not_use():
     """wgrad operands as the LAST column blocks of packed buffers whose other columns are NaN, with M and N that leave
     edge tiles: the tile is fetched without a column predicate, so NaNs from beyond the valid columns sit in LDS — they
