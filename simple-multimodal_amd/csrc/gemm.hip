@@ -52,10 +52,12 @@ static const int g_tn6 = [] { const char* e = getenv("MMF_GEMM_TN6"); return e ?
 static const int g_g6_maxtiles = [] { const char* e = getenv("MMF_GEMM6_MAXTILES"); return e ? atoi(e) : 1 << 30; }();
 static const int g_longk6 = [] { const char* e = getenv("MMF_GEMM_LONGK6"); return e ? atoi(e) : 512; }();   // round 3 default: every K >= 512 launch
 static const int g_policy = [] { const char* e = getenv("MMF_GEMM_POLICY"); return e ? atoi(e) : 2; }();
-// round 4: NT / NN launches that gemm6 would take go to its persistent form (gemm7.hip) when the launch has more tiles than
-// MMF_GEMM_PERSIST_MINTILES (default: the CU count, i.e. some workgroup walks at least two tiles); MMF_GEMM_PERSIST=0: off
+// round 4: every NT / NN launch that gemm6 would take goes to its persistent form (gemm7.hip) if that kernel has the launch's flag set
+// (mmf_gemm7_supports); MMF_GEMM_PERSIST=0: off.  MMF_GEMM_PERSIST_MINTILES (default 0): only launches with more tiles than this —
+// launches of at most one tile per CU gain from gemm7's drain (outputs and aux through LDS as whole rows) alone: +4 ... +29 % on the
+// step's one-round groups (profiles/r04_gemm7_vs_gemm6.txt)
 static int g_persist = [] { const char* e = getenv("MMF_GEMM_PERSIST"); return e ? atoi(e) : 1; }();
-static const int g_persist_min = [] { const char* e = getenv("MMF_GEMM_PERSIST_MINTILES"); return e ? atoi(e) : -1; }();
+static const int g_persist_min = [] { const char* e = getenv("MMF_GEMM_PERSIST_MINTILES"); return e ? atoi(e) : 0; }();
 static int auto_impl(const mmf_gemm_problem* p, int n, int layout, bool allow6 = true) {
   if (layout == MMF_GEMM_TN) {
     if (g_tn5) return 5;
@@ -142,8 +144,7 @@ extern "C" int mmf_gemm_grouped_ex(const mmf_gemm_problem* problems, int num_pro
   if (impl == 6 && gemm_impl() == 0 && g_persist && mmf_gemm7_supports(problems, num_problems, layout, epilogue, out_f32, extra)) {
     long tiles = 0;
     for (int i = 0; i < num_problems; ++i) tiles += (long)((problems[i].M + 255) / 256) * ((problems[i].N + 255) / 256);
-    static const int cus7 = [] { int c = mmf_device_cu_count(); return c > 0 ? c : 256; }();
-    if (tiles > (g_persist_min >= 0 ? g_persist_min : cus7)) impl = 7;
+    if (tiles > g_persist_min) impl = 7;
   }
   if (impl == 7 && !mmf_gemm7_supports(problems, num_problems, layout, epilogue, out_f32, extra))
     impl = mmf_gemm6_supports(problems, num_problems, layout) && mmf_gemm6_supports_epi(epilogue, out_f32) ? 6 : auto_impl(problems, num_problems, layout, false);

@@ -328,6 +328,10 @@ __device__ __forceinline__ void gemm7_body(const GemmArgs& args, const int total
   auto mf = [&](const Frag4<A_KR>& a, const Frag4<B_KR>& b, int i) {
     const int tm = i >> 2, tn = i & 3;
     acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b.get(tn), a.get(tm), acc[tn][tm], 0, 0, 0);
+    // an empty statement that "uses" the tile: the MFMA builtin has no side effect, and in this kernel instruction selection sank the
+    // sixteen MFMAs of a substep below the reads and pieces that are written between them (each down to its next use, the same
+    // tile's MFMA of the following substep); the volatile statement chains it into the order of the other asm statements
+    asm volatile("" ::"a"(acc[tn][tm]));
     __builtin_amdgcn_sched_barrier(0);
   };
 #define MMF_G7_READ(dstA, dstB, G, u, so)                                                              \
@@ -344,10 +348,12 @@ __device__ __forceinline__ void gemm7_body(const GemmArgs& args, const int total
   } while (0)
 
   // One stage (gemm6.hip's schedule, BK = 32: two k-substeps of sixteen MFMAs).  g: the workgroup's running stage count (ring slot
-  // g % NS).  do_switch: this is stage KT - NS of its tile — from its hand-over on the refills fetch the NEXT tile (or nothing).
+  // g % NS).  kt == ksw: this is stage KT - NS of its tile — from its hand-over on the refills fetch the NEXT tile (or nothing).
   // The hand-over counts PIECES only.  Stores, aux and bias loads of a drain may be younger than the pieces waited for: the wait
   // then covers more than it needs (safe whether or not the hardware retires loads and stores in one order), never less.
-  auto stage = [&](const unsigned g, const bool do_switch) {
+  auto stage = [&](const unsigned g, const int kt, const int ksw) {
+    unsigned long long swmask;
+    const Desc nA = mkdesc(ns.Ab, ns.recA), nB = mkdesc(ns.Bb, ns.recB);
     const unsigned so = (g % NS) * STAGE;
     const unsigned ring_cur = lds_pieces + so, ring_prev = lds_pieces + ((g + NS - 1) % NS) * STAGE;
     // substep 0: MFMA i (i < 8) is followed by one read of substep 1's fragments; the early pieces (second half of the stage whose
@@ -369,24 +375,47 @@ __device__ __forceinline__ void gemm7_body(const GemmArgs& args, const int total
     for (int i = 0; i < 4; ++i) mf(fa[1], fb[1], i);
     vm_wait<PPW * (NS - 2)>();
     __builtin_amdgcn_s_barrier();                              // the next stage landed for everyone; nobody reads this one any more
-    // advance, or switch to the next tile's first stage: as SELECTS, not as a branch — with a branch here hipcc duplicated the rest of
-    // the stage into both arms and joined the two copies' 256 accumulator registers with v_accvgpr_mov chains behind the k-loop
-    {
-      Desc a2 = dA, b2 = dB;
-      advance(a2, stepA);
-      advance(b2, stepB);
-      const Desc an = mkdesc(ns.Ab, ns.recA), bn = mkdesc(ns.Bb, ns.recB);
-      dA.lo = do_switch ? an.lo : a2.lo; dA.hi = do_switch ? an.hi : a2.hi; dA.rec = do_switch ? an.rec : a2.rec;
-      dB.lo = do_switch ? bn.lo : b2.lo; dB.hi = do_switch ? bn.hi : b2.hi; dB.rec = do_switch ? bn.rec : b2.rec;
-      stepB = do_switch ? ns.stepB : stepB;
-#pragma unroll
-      for (int i = 0; i < PPW; ++i) voff[i] = do_switch ? voffn[i] : voff[i];
-    }
     __builtin_amdgcn_sched_barrier(0);
+    // Behind the hand-over: advance the descriptors, or switch them (and the per-lane offsets) to the next tile's first stage — as
+    // SELECTS, not as a branch (with a branch here hipcc duplicated the rest of the stage into both arms and joined the two copies'
+    // 256 accumulator registers with v_accvgpr_mov chains behind the k-loop), in four portions of at most nine instructions behind
+    // MFMAs 4..7 (a wave issues eight instructions per 32-cycle MFMA).  The selects are inline asm: ONE compare feeds all of them
+    // (hipcc re-derived the condition per portion: 45 instructions), and left to itself it computes all of it between the vmcnt
+    // wait and the barrier, in front of an idle matrix pipe.
 #pragma unroll
     for (int i = 4; i < 16; ++i) {
       mf(fa[1], fb[1], i);
       if (i < 12) MMF_G7_READ(fa[0], fb[0], 0, i - 4, sn);
+      if (i == 4) {                                            // both descriptors one stage on (eight scalar instructions)
+        advance(dA, stepA);
+        advance(dB, stepB);
+        asm volatile("" ::"s"(dA.lo), "s"(dA.hi), "s"(dA.rec), "s"(dB.lo), "s"(dB.hi), "s"(dB.rec));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (i == 5) {                                            // one compare, seven scalar selects, the lane mask for the vector selects
+        asm volatile("s_cmp_eq_u32 %8, %16\n\t"
+                     "s_cselect_b32 %0, %9, %0\n\ts_cselect_b32 %1, %10, %1\n\ts_cselect_b32 %2, %11, %2\n\t"
+                     "s_cselect_b32 %3, %12, %3\n\ts_cselect_b32 %4, %13, %4\n\ts_cselect_b32 %5, %14, %5\n\t"
+                     "s_cselect_b32 %6, %15, %6\n\ts_cselect_b64 %7, -1, 0"
+                     : "+s"(dA.lo), "+s"(dA.hi), "+s"(dA.rec), "+s"(dB.lo), "+s"(dB.hi), "+s"(dB.rec), "+s"(stepB), "=s"(swmask)
+                     : "s"(kt), "s"(nA.lo), "s"(nA.hi), "s"(nA.rec), "s"(nB.lo), "s"(nB.hi), "s"(nB.rec), "s"(ns.stepB), "s"(ksw)
+                     : "scc");
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (i == 6) {
+        asm volatile("v_cndmask_b32_e64 %0, %0, %4, %8\n\tv_cndmask_b32_e64 %1, %1, %5, %8\n\t"
+                     "v_cndmask_b32_e64 %2, %2, %6, %8\n\tv_cndmask_b32_e64 %3, %3, %7, %8"
+                     : "+v"(voff[0]), "+v"(voff[1]), "+v"(voff[2]), "+v"(voff[3])
+                     : "v"(voffn[0]), "v"(voffn[1]), "v"(voffn[2]), "v"(voffn[3]), "s"(swmask));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (i == 7) {
+        asm volatile("v_cndmask_b32_e64 %0, %0, %4, %8\n\tv_cndmask_b32_e64 %1, %1, %5, %8\n\t"
+                     "v_cndmask_b32_e64 %2, %2, %6, %8\n\tv_cndmask_b32_e64 %3, %3, %7, %8"
+                     : "+v"(voff[4]), "+v"(voff[5]), "+v"(voff[6]), "+v"(voff[7])
+                     : "v"(voffn[4]), "v"(voffn[5]), "v"(voffn[6]), "v"(voffn[7]), "s"(swmask));
+        __builtin_amdgcn_sched_barrier(0);
+      }
       if (i == 12) hot_piece(std::integral_constant<int, 0>{}, ring_cur);
       if (i == 13) hot_piece(std::integral_constant<int, 1>{}, ring_cur);
       if (i == 14) hot_piece(std::integral_constant<int, 2>{}, ring_cur);
@@ -400,7 +429,7 @@ __device__ __forceinline__ void gemm7_body(const GemmArgs& args, const int total
   for (;;) {
     bias_init(bcur);
     const int ksw = KT - NS;                                   // >= 1 (host)
-    for (int kt = 0; kt < KT; ++kt, ++g) stage(g, kt == ksw);
+    for (int kt = 0; kt < KT; ++kt, ++g) stage(g, kt, ksw);
     // ---- the tile's outputs ----------------------------------------------------------------------------------------------------------
     const mmf_gemm_problem& P = args.p[cd.pi];
     const int mb = cd.m0 + 128 * wm, nb = cd.n0 + 128 * wn;

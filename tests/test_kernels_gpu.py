@@ -257,9 +257,9 @@ def test_gemm7_persistent_walks_tiles_bit_identical_to_gemm6(layout, wgs):
                 assert torch.equal(a, b), f"epi {epi} problem {i}: generation 7 differs from generation 6"
 
 
-def test_gemm7_is_the_automatic_choice_for_multi_round_launches():
-    """automatic rule: an NT launch with more 256 x 256 tiles than CUs and K >= 512 goes to the persistent kernel, a one-round launch and
-    an f32-output launch stay on generation 6"""
+def test_gemm7_is_the_automatic_choice_where_it_has_the_flag_set():
+    """automatic rule: an NT / NN launch gemm6 would take (K >= 512, at least half of the CUs get a 256 x 256 tile) goes to the persistent
+    kernel when it has the launch's flag set; f32 output and flag sets it lacks stay on generation 6"""
     L = lib.load()
     cus = L.mmf_device_cu_count()
     rows = 256 * (cus // 3 + 1)                                   # x 3 column tiles > CUs
@@ -268,11 +268,14 @@ def test_gemm7_is_the_automatic_choice_for_multi_round_launches():
     ops.gemm(GEMM_NT, a, w, c)
     assert L.mmf_gemm_last_impl() == 7
     assert rel(c, a.float().cpu() @ w.float().cpu().t()) < 2 ** -8
-    half = rows // 2 // 256 * 256
-    ops.gemm(GEMM_NT, a[:half], w, c[:half])
-    assert L.mmf_gemm_last_impl() == 6
+    half = rows // 2 // 256 * 256 + 256
+    ops.gemm(GEMM_NT, a[:half], w, c[:half])                       # one round, more than half of the CUs
+    assert L.mmf_gemm_last_impl() == 7
     cf = torch.empty((rows, 768), device=DEV)
-    ops.gemm(GEMM_NT, a, w, cf)
+    ops.gemm(GEMM_NT, a, w, cf)                                    # f32 output
+    assert L.mmf_gemm_last_impl() == 6
+    aux = bf(rnd(rows, 768, seed=3))
+    ops.gemm(GEMM_NT, a, w, c, aux=aux, epilogue=EPI_MASK_AUX)     # a flag set only the NN form has
     assert L.mmf_gemm_last_impl() == 6
 
 
