@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — fusion fwd+bwd samples/s (BASELINE.json metric) on N MI355X of one node.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload mult|hier|train] [--no-graph]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload mult|hier|train|meld] [--no-graph]
                     [--no-cpu-baseline] [--frozen-inputs]
     N > 1: either the driver's `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...`
     or plain `python bench.py --gpus N`, which starts exactly that launcher as a CHILD process before anything in this
@@ -23,8 +23,15 @@ Inputs are resident in HBM before the timed region.  Steps are replayed from one
 hipGraph unless --no-graph.  Rank 0 prints ONE JSON line.
 
 roofline: HIP-event durations of every grouped GEMM / attention launch are collected in a
-separate eager pass after the timed region (same process, same shapes); the dominant kernel is
-the label with the largest total time; achieved = its algorithmic FLOPs / its time.
+separate eager pass after the timed region (same process, same shapes).  `roofline` names the kernel label
+with the largest time SUMMED over its launches of a step (the rule of rounds 1-2; round 3 had switched to the longest
+single launch in commit 71e2ace — that number is still reported, as `roofline_longest_launch`, beside
+`roofline_gemm_all`: every grouped-GEMM launch of the step together); achieved = algorithmic FLOPs / time.
+N > 1: after the headline region the same process group also times the hierarchical-fusion TRAINING step (the workload
+of the north_star's scaling target, BASELINE configs[3]) and attaches it as `scaling_train`.
+--workload meld: BASELINE configs[4], the path the reference really runs (pooled (B, 768) features -> Linear(768, 512)
+-> ModalityDropout -> hierarchical fusion at d = 512, T = 1 -> classifier -> CE(ls 0.1) + 0.1 contrastive -> clip +
+AdamW); HBM / launch bound: its roofline is bytes (parameters, gradients, optimiser state streamed once) over time.
 step_tflops = the algorithmic FLOPs of the GEMM / attention problems ACTUALLY launched in one step (summed per launch
 in that pass: 2MNK per GEMM problem, 4 / 8 Tq Tk d per attention problem fwd / bwd) / step time.
 cpu_baseline: oracle/ref_cpu.py (fp32, all host cores) timed on rank 0 at N = 1 on the same
@@ -98,6 +105,47 @@ def build(workload, device, rank, dropout=0.0, input_grads=True):
     return cfg, model, xs
 
 
+def build_meld(device, rank, dropout=0.1):
+    """BASELINE configs[4]: per rank 3 x randn(16, 768) encoder features (seed 1234 + rank) ->
+    Linear(768, 512) + dropout -> ModalityDropout(0.1) -> HierarchicalFusion(d = 512, H = 8, G = 512, L = 3) at T = 1 ->
+    EmotionClassifier -> 7 classes.  Reference: models/multimodal_model.py:95-101,130-134 (projection tails and glue),
+    training/advanced_trainer.py:139-182 (loss, clip, optimiser)."""
+    import config as cfgmod
+    from mmfusion import ops, synth
+    from models import fusion_layers as fl
+    from models.encoders import ModalityDropout
+    from models.multimodal_model import EmotionClassifier
+    cfg = cfgmod.ModelConfig()
+    cfg.fusion_hidden_size, cfg.fusion_num_heads, cfg.fusion_dropout = 512, 8, dropout
+    cfg.graph_hidden_size, cfg.graph_num_layers, cfg.graph_dropout = 512, 3, dropout
+    torch.manual_seed(synth.WEIGHT_SEED)
+
+    class MeldShaped(fl._FusionBase):
+        def __init__(self):
+            super().__init__()
+            self.config = cfg
+            self.text_projection = torch.nn.Linear(768, 512)
+            self.audio_projection = torch.nn.Linear(768, 512)
+            self.video_projection = torch.nn.Linear(768, 512)
+            self.modality_dropout = ModalityDropout(0.1)
+            self.fusion_layer = fl.HierarchicalFusion(cfg)
+            self.classifier = EmotionClassifier(cfg)
+
+        def forward(self, t, a, v, compute_contrastive_loss=False):
+            p = fl._p(self, cfg.fusion_dropout)
+            items = [(fl._as_rows(x), fl._lin(lin), None) for x, lin in
+                     ((t, self.text_projection), (a, self.audio_projection), (v, self.video_projection))]
+            feats = [ops.dropout(y, p, True) for y in ops.linear_group(items, out_f32=True)]
+            feats = self.modality_dropout(*feats, training=self.training)
+            out = dict(self.fusion_layer(*feats, compute_contrastive_loss=compute_contrastive_loss))
+            out["emotion_logits"] = self.classifier(out["fused_features"])
+            return out
+    model = MeldShaped().to(device).train()
+    g = torch.Generator().manual_seed(synth.INPUT_SEED + rank)
+    xs = [torch.randn(16, 768, generator=g).to(device) for _ in range(3)]
+    return cfg, model, xs
+
+
 def make_train_step(model, xs, arena, world, allreduce, rank, shard_optimizer=False):
     """hierarchical-fusion TRAINING step (BASELINE configs[3]): zero grads, forward, CE(ls=0.1) + 0.1 *
     contrastive, backward | RCCL all-reduce | clip(1.0) + AdamW (fused, also refreshes the bf16 shadow)."""
@@ -129,7 +177,43 @@ def make_train_step(model, xs, arena, world, allreduce, rank, shard_optimizer=Fa
     def exchange():
         if world > 1 and not opt.sharded:
             dp.allreduce_grads(arena, compress=None if allreduce == "fp32" else "bf16")
+    EXTRAS["opt_launch"], EXTRAS["opt"] = opt_launch, opt
     return fwd_bwd, before_replay, exchange, opt_launch, opt.sharded
+
+
+EXTRAS = {}
+
+
+def meld_report(line, arena, ms_per_step, extras):
+    """BASELINE configs[4] is HBM / launch bound (every GEMM has 16 rows): its roofline is bytes over time.
+    Algorithmic bytes per parameter and step: bf16 weight read in forward (2) and in the input-gradient pass (2), f32 gradient
+    written (4); clip + AdamW reads gradient, master, both moments (16) and writes master, both moments and the bf16 shadow (14):
+    38 B.  `roofline` = the dominant kernel, the fused AdamW pass (30 B / parameter), timed here with HIP events on its own."""
+    opt_launch = extras.get("opt_launch")
+    n = arena.numel
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(3):
+        opt_launch()
+    e0.record()
+    reps = 20
+    for _ in range(reps):
+        opt_launch()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / reps
+    ach = 30.0 * n / (us * 1e-6) / 1e9
+    line["metric"] = "MELD-shaped fusion training step samples/sec at B=16 d=512"
+    line["roofline"] = {"bound": "hbm", "kernel": "sqnorm_kernel + adamw_step_kernel (clip + AdamW over the flat arenas)",
+                        "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                        "traffic": None, "avg_launch_us": round(us, 2), "parameters": n,
+                        "algorithmic_bytes": "30 B / parameter: gradient, master, exp_avg, exp_avg_sq read; master, both moments, "
+                                             "bf16 shadow written"}
+    step_bytes = 38.0 * n
+    line["roofline_step"] = {"bound": "hbm", "achieved": round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                             "unit": "GB/s", "frac": round(step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                             "algorithmic_bytes": "38 B / parameter and step (weights read twice as bf16, f32 gradient written, AdamW 30)"}
+    line.pop("roofline_longest_launch", None)
+    line.pop("roofline_gemm_all", None)
 
 
 def make_step(workload, model, xs, arena):
@@ -216,6 +300,36 @@ def cpu_baseline(workload):
                       f"steps ({best:.2f} s/step) on {model_name}"}
 
 
+def cpu_baseline_meld(model):
+    """the MELD-shaped step on the oracle (fp32 CPU restatement, dropout 0): projections + hier-ref fusion + classifier +
+    loss, forward and backward, and torch's AdamW step over the same parameters; best of 3 after one warm-up."""
+    from oracle import ref_cpu
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    P = {k: v.detach().float().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(1234)
+    xs = [torch.randn(16, 768, generator=g) for _ in range(3)]
+    labels = torch.randint(0, 7, (16,), generator=torch.Generator().manual_seed(99))
+    opt = torch.optim.AdamW(list(P.values()), lr=1e-4, weight_decay=1e-5)
+    best = float("inf")
+    for i in range(4):
+        opt.zero_grad(set_to_none=True)
+        t0 = time.perf_counter()
+        t, a, v = (ref_cpu.linear(x, P[f"{m}_projection.weight"], P[f"{m}_projection.bias"]) for x, m in zip(xs, ("text", "audio", "video")))
+        fo = ref_cpu.hierarchical_fusion(P, "fusion_layer.", t, a, v, num_heads=8, graph_num_layers=3, temperature=0.07,
+                                         compute_contrastive_loss=True)
+        logits = ref_cpu.emotion_classifier(P, "classifier.", fo["fused_features"])
+        loss = torch.nn.functional.cross_entropy(logits, labels, label_smoothing=0.1) + 0.1 * sum(fo["contrastive_losses"].values())
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_([p for p in P.values() if p.grad is not None], 1.0)
+        opt.step()
+        dt = time.perf_counter() - t0
+        if i > 0:
+            best = min(best, dt)
+    return {"value": round(16 / best, 2), "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/ref_cpu.py MELD-shaped training step fp32 (dropout 0), B=16, best of 3 steps ({best * 1e3:.1f} ms/step)"}
+
+
 _SYMBOL = {"gemm4_grouped_kernel<NT,bf16>": ["gemm4_grouped_kernel<false, false, false>"],
            "gemm2_grouped_kernel<NT,bf16>": ["gemm2_grouped_kernel<false, false, false>"],
            "gemm5_grouped_kernel<NT,bf16>": ["gemm5_grouped_kernel<false, false, false>", "gemm5_grouped_kernel<false>"],
@@ -228,6 +342,10 @@ _SYMBOL = {"gemm4_grouped_kernel<NT,bf16>": ["gemm4_grouped_kernel<false, false,
            "gemm6_grouped_kernel<TN,f32>": ["gemm6_grouped_kernel<true, true, 32, 4, true>"],
            "gemm6_grouped_kernel<NT,bf16>": ["gemm6_grouped_kernel<false, false, 32, 4, false>"],
            "gemm6_grouped_kernel<NN,bf16>": ["gemm6_grouped_kernel<false, true, 32, 4, false>"],
+           "gemm7_grouped_kernel<NT,bf16>": ["gemm7_persistent_kernel<false, 0>", "gemm7_persistent_kernel<false, 1>",
+                                             "gemm7_persistent_kernel<false, 3>", "gemm7_persistent_kernel<false, 9>"],
+           "gemm7_grouped_kernel<NN,bf16>": ["gemm7_persistent_kernel<true, 0>", "gemm7_persistent_kernel<true, 4>",
+                                             "gemm7_persistent_kernel<true, 8>"],
            "attn_fwd_kernel<96>": ["attn_fwd2n_kernel<96, false>", "attn_fwd2_kernel<96, false, 2>", "attn_fwd2_kernel<96, false>"],
            "attn_bwd_kernels<96>": ["attn_bwd_dq2_kernel<96, false>", "attn_bwd_dkv2_kernel<96, false>"]}
 
@@ -338,9 +456,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", choices=["mult", "hier", "train"], default="mult",
+    ap.add_argument("--workload", choices=["mult", "hier", "train", "meld"], default="mult",
                     help="mult: MulT fwd+bwd (BASELINE configs[1], the headline); hier: hier-seq fwd+bwd "
-                         "(configs[2]); train: hier-seq training step incl. fused clip+AdamW (configs[3])")
+                         "(configs[2]); train: hier-seq training step incl. fused clip+AdamW (configs[3]); meld: the "
+                         "MELD-shaped training step on pooled (16, 768) features (configs[4])")
+    ap.add_argument("--no-scaling-train", action="store_true",
+                    help="N > 1: do not time the hierarchical-fusion training step after the headline region")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--recast-weights", action="store_true",
@@ -392,11 +513,16 @@ def main():
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
+    if world > 1 and args.backend == "nccl":
+        os.environ.setdefault("MMF_DP_STRICT", "1")     # a scaling run on RCCL must not silently measure a fallback schedule
     from mmfusion import arena as arena_mod, dp, synth
     if args.recast_weights:
         from models import fusion_layers as _flm
         _flm._RECAST = True
-    cfg, model, xs = build(args.workload, device, rank, args.dropout, input_grads=not args.frozen_inputs)
+    if args.workload == "meld":
+        cfg, model, xs = build_meld(device, rank, args.dropout if args.dropout > 0 else 0.1)
+    else:
+        cfg, model, xs = build(args.workload, device, rank, args.dropout, input_grads=not args.frozen_inputs)
     arena = arena_mod.ensure(model)
     use_graph = not args.no_graph
     compress = None if args.allreduce == "fp32" else "bf16"
@@ -487,11 +613,12 @@ def main():
         for h in handles:
             h.finish()
 
-    def make_runner(model, xs, arena):
+    def make_runner(model, xs, arena, workload=None):
         """-> (run_step: one timed step incl. the exchange, profile_step: the same work WITHOUT any collective, overlap flag)"""
+        workload = workload or args.workload
         overlap = want_overlap
         graph = graph2 = split = None
-        if args.workload == "train":
+        if workload in ("train", "meld"):
             fwd_bwd, before_replay, exchange, opt_launch, sharded = make_train_step(model, xs, arena, world, args.allreduce,
                                                                                     rank, args.shard_optimizer)
             if sharded:
@@ -532,7 +659,7 @@ def main():
                 else:
                     eager_step()
             return run_step, profile_step, overlap
-        eager_step = make_step(args.workload, model, xs, arena)
+        eager_step = make_step(workload, model, xs, arena)
         if overlap:
             split = try_capture_split(eager_step)
             overlap = split is not None
@@ -557,6 +684,27 @@ def main():
         torch.cuda.synchronize()
     elapsed = timed_region(run_step, args.steps, args.warmup, world, dist, torch.cuda.synchronize,
                            device if args.backend == "nccl" else "cpu")
+
+    # N > 1: the north_star's scaling target is the hierarchical-fusion TRAINING step (BASELINE configs[3]), not the headline MulT
+    # step — time it here, inside the same process group, so that one SCALE run carries both numbers.  Every rank runs this.
+    scaling_train = None
+    if world > 1 and args.workload == "mult" and not args.no_scaling_train:
+        _, model_t, xs_t = build("train", device, rank, args.dropout, input_grads=True)
+        arena_t = arena_mod.ensure(model_t)
+        fb_before = fallback["reason"]
+        fallback["reason"] = None
+        run_t, _, overlap_t = make_runner(model_t, xs_t, arena_t, "train")
+        steps_t, warm_t = max(1, min(args.steps, 50)), max(1, min(args.warmup, 10))
+        e_t = timed_region(run_t, steps_t, warm_t, world, dist, torch.cuda.synchronize,
+                           device if args.backend == "nccl" else "cpu")
+        scaling_train = {"metric": "hierarchical-fusion training step samples/sec at B=16/GPU d=768", "unit": "samples/s",
+                         "value": round(world * 16 * steps_t / e_t, 2), "ms_per_step": round(e_t / steps_t * 1e3, 4),
+                         "steps": steps_t, "warmup": warm_t, "n_gpus": world, "scaling": "weak", "parallelism": f"dp{world}",
+                         "sharded_optimizer": bool(args.shard_optimizer), "allreduce_overlaps_wgrad": bool(overlap_t),
+                         "overlap_fallback": fallback["reason"], "grad_allreduce": args.allreduce,
+                         "strict": os.environ.get("MMF_DP_STRICT") == "1"}
+        fallback["reason"] = fb_before
+        del model_t, xs_t, arena_t, run_t
 
     # optional (MMF_BENCH_CHECKSUM=1): f64 |.|-sum and sum of the gradient arena after the last timed step, to compare
     # exchange schedules (overlapped vs one-shot all-reduce) on the same inputs
@@ -583,20 +731,31 @@ def main():
     _fl._MULT_STREAMS, _fl._BRANCH_STREAM, _ops._WGRAD_EARLY = 1, False, False
     prof = kernel_profile(profile_step, args.profile_steps)
     _fl._MULT_STREAMS, _fl._BRANCH_STREAM, _ops._WGRAD_EARLY = saved_streams
-    # the dominant kernel = the kernel with the longest launch (average duration per launch): the deferred wgrad launch, which runs
-    # alone on the chip after the streams have joined — the one kernel whose duration in a rocprofv3 summary of the timed command
-    # equals its stand-alone duration.  (By time summed over a label's launches the three NN dgrad launches of the 256 x 256 kernel
-    # together are level with it since round 3; they share the chip with the other stream's kernels.)
-    dom = max(prof, key=lambda k: prof[k]["ms_total"] / max(1, prof[k]["launches"]))
-    dsec = prof[dom]["ms_total"] * 1e-3
-    ach = prof[dom]["flops_total"] / dsec / 1e12
-    # the committed PMC passes are of the MulT workload: its per-launch byte counts do not describe the other workloads' launches
-    traffic, mfma_util, pmc_src = pmc_lookup(dom) if args.workload == "mult" else (None, None, None)
-    roofline = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": BF16_MFMA_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                "mfma_util_pmc": mfma_util, "traffic_and_util_source": pmc_src,
-                "avg_launch_us": round(prof[dom]["ms_total"] * 1e3 / prof[dom]["launches"], 2),
-                "launches_per_step": prof[dom]["launches"] // args.profile_steps}
+    def roof(labels, name=None):
+        """roofline object of one kernel label, or of several taken together (their FLOPs and times summed)"""
+        ms = sum(prof[k]["ms_total"] for k in labels)
+        fl = sum(prof[k]["flops_total"] for k in labels)
+        n = sum(prof[k]["launches"] for k in labels)
+        a = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        r = {"bound": "mfma", "kernel": name or labels[0], "achieved": round(a, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+             "frac": round(a / BF16_MFMA_PEAK_TFLOPS, 4), "us_per_step": round(ms * 1e3 / args.profile_steps, 1),
+             "avg_launch_us": round(ms * 1e3 / max(1, n), 2), "launches_per_step": n // args.profile_steps}
+        if len(labels) == 1 and args.workload == "mult":
+            # the committed PMC passes are of the MulT workload: its per-launch byte counts do not describe the other workloads' launches
+            r["traffic"], r["mfma_util_pmc"], r["traffic_and_util_source"] = pmc_lookup(labels[0])
+        else:
+            r["traffic"] = None
+        return r
+    # `roofline`: the kernel label with the largest time summed over its launches of a step (rounds 1-2's rule, restored in round 4;
+    # round 3's line named the longest single launch instead — commit 71e2ace — which is the deferred wgrad launch: it runs alone
+    # on the chip after the streams have joined, so its rocprofv3 duration in the timed command equals its stand-alone duration,
+    # while the NT / NN launches share the chip with the other stream's kernels there and read longer than in this stand-alone pass).
+    gemm_labels = sorted(k for k in prof if k.startswith("gemm"))
+    dom = max(prof, key=lambda k: prof[k]["ms_total"])
+    longest = max(prof, key=lambda k: prof[k]["ms_total"] / max(1, prof[k]["launches"]))
+    roofline = roof([dom])
+    roofline_longest = roof([longest])
+    roofline_gemm_all = roof(gemm_labels, "all grouped GEMM launches of the step (" + ", ".join(gemm_labels) + ")") if gemm_labels else None
     kernels = {k: {"us_per_step": round(v["ms_total"] * 1e3 / args.profile_steps, 1),
                    "tflops": round(v["flops_total"] / (v["ms_total"] * 1e-3) / 1e12, 1) if v["ms_total"] > 0 else None,
                    "gflop_per_step": round(v["flops_total"] / args.profile_steps / 1e9, 1),
@@ -607,9 +766,13 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
         "data": "synthetic",
-        "config": {"workload": {"mult": "MulT fwd+bwd", "hier": "hier-seq fwd+bwd",
-                                "train": "hier-seq training step (fwd+bwd+clip+AdamW)"}[args.workload] +
-                               f", B=16/GPU, T_text=512 T_audio=400 T_frames=30 d=768 H=8, fusion_dropout={args.dropout:g}",
+        "config": {"workload": ({"mult": "MulT fwd+bwd", "hier": "hier-seq fwd+bwd",
+                                 "train": "hier-seq training step (fwd+bwd+clip+AdamW)"}[args.workload] +
+                                f", B=16/GPU, T_text=512 T_audio=400 T_frames=30 d=768 H=8, fusion_dropout={args.dropout:g}")
+                               if args.workload != "meld" else
+                               "MELD-shaped training step (BASELINE configs[4]): 3 x (16, 768) features -> Linear(768, 512) -> "
+                               "ModalityDropout(0.1) -> hierarchical fusion d=512 H=8 G=512 L=3 at T=1 -> classifier(7) -> "
+                               "CE(ls 0.1) + 0.1 contrastive -> clip(1.0) + AdamW, B=16/GPU, dropout 0.1",
                    "input_gradients": not args.frozen_inputs,
                    "weight_shadow": "re-cast every step" if args.recast_weights else "cached while the masters are unchanged",
                    "global_batch": B * world, "parallelism": f"dp{world}",
@@ -620,8 +783,14 @@ def main():
         "step_gflop_launched": round(launched_flops / 1e9, 1),
         "step_tflops": round(launched_flops / (ms_per_step * 1e-3) / 1e12, 1),
         "roofline": roofline,
+        "roofline_longest_launch": roofline_longest,
+        "roofline_gemm_all": roofline_gemm_all,
         "kernels": kernels,
     }
+    if scaling_train is not None:
+        line["scaling_train"] = scaling_train
+    if args.workload == "meld":
+        meld_report(line, arena, ms_per_step, EXTRAS)
     af = prof.get("attn_fwd_kernel<96>")
     if af and af["ms_total"] > 0:
         # the north_star's named kernel: the MulT attention cores.  At these shapes the cores sit below the
@@ -649,6 +818,8 @@ def main():
         del model2, xs2, arena2, run2
     if world == 1 and not args.no_cpu_baseline and args.workload == "mult":
         line["cpu_baseline"] = cpu_baseline(args.workload)
+    if world == 1 and not args.no_cpu_baseline and args.workload == "meld":
+        line["cpu_baseline"] = cpu_baseline_meld(model)
     if checksum is not None:
         line["grad_checksum"] = checksum
     print(json.dumps(line), flush=True)

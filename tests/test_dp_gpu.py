@@ -40,6 +40,15 @@ def test_overlapped_exchange_leaves_the_same_gradients_as_the_one_shot_exchange(
     b = _bench("0", base + 1)
     assert a["config"]["allreduce_overlaps_wgrad"] is True and a["config"]["overlap_fallback"] is None
     assert b["config"]["allreduce_overlaps_wgrad"] is False
+    # round 4: an N > 1 run also times the hierarchical-fusion TRAINING step (the north_star's scaling workload) inside the same
+    # process group and attaches it to the line
+    for line, ov in ((a, True), (b, False)):
+        st = line["scaling_train"]
+        assert st["n_gpus"] == 2 and st["parallelism"] == "dp2" and st["value"] > 0 and st["ms_per_step"] > 0
+        assert st["allreduce_overlaps_wgrad"] is ov and st["overlap_fallback"] is None and st["strict"] is True
+        assert {"sharded_optimizer", "grad_allreduce", "steps", "warmup", "scaling"} <= set(st)
+    for key in ("roofline", "roofline_longest_launch", "roofline_gemm_all"):
+        assert a[key]["frac"] > 0 and a[key]["unit"] == "TFLOP/s"
     (abs_a, sum_a), (abs_b, sum_b) = a["grad_checksum"], b["grad_checksum"]
     assert abs(abs_a - abs_b) <= 1e-9 * abs_b and abs(sum_a - sum_b) <= 1e-9 * abs_b, (a["grad_checksum"], b["grad_checksum"])
 
