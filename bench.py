@@ -133,9 +133,9 @@ def build_meld(device, rank, dropout=0.1):
 
         def forward(self, t, a, v, compute_contrastive_loss=False):
             p = fl._p(self, cfg.fusion_dropout)
-            items = [(fl._as_rows(x), fl._lin(lin), None) for x, lin in
+            items = [(x, fl._lin(lin), None) for x, lin in            # f32 (16, 768) rows: narrowed, projected and dropped out in one launch
                      ((t, self.text_projection), (a, self.audio_projection), (v, self.video_projection))]
-            feats = [ops.dropout(y, p, True) for y in ops.linear_group(items, out_f32=True)]
+            feats = ops.linear_group(items, out_f32=True, dropout_p=p)
             feats = self.modality_dropout(*feats, training=self.training)
             out = dict(self.fusion_layer(*feats, compute_contrastive_loss=compute_contrastive_loss))
             out["emotion_logits"] = self.classifier(out["fused_features"])

@@ -145,6 +145,37 @@ typedef struct mmf_skinny_problem {
 int mmf_skinny_linear_fwd(const mmf_skinny_problem* problems, int num_problems, int flags, int out_f32, void* stream);
 int mmf_skinny_linear_dgrad(const mmf_skinny_problem* problems, int num_problems, int flags, float alpha, int out_f32,
                             void* stream);
+/* Round 4: the launches AROUND a (B, d)-row linear folded into it — these rows cost a launch (~5 us) per kernel, not bandwidth
+ * (models/fusion_layers.py:21-28,304-327,395-412,471-476: every Linear there is followed by ReLU and / or Dropout and fed by a cat
+ * or a pooled f32 tensor).
+ *   forward  X may be f32 (narrowed while loaded); MMF_EPI_DROPOUT: Y = dropout(act(X W^T + b)) with the build's counter-based
+ *            masks (element m * N + n of stream `site`, problem i); Y2: a second copy of the output in the OTHER dtype (the bf16
+ *            operand of the next linear beside the f32 value the module returns), or NULL; with an f32 X, `dz` (if not NULL)
+ *            receives the narrowed input as bf16 [M][lddz] — the weight gradient's other operand.
+ *   dgrad    dz = dY * (gate > 0) * gate_scale [* keep / (1 - p) with MMF_EPI_DROPOUT: the mask of the forward with the same site]
+ *            is formed while dY (bf16 or f32) is loaded — gate = the forward's saved output (ReLU, or ReLU + dropout whose dropped
+ *            units are exactly 0: gate_scale = 1 / (1 - p)) — and dx = dz W; `dz` (bf16, lddz) receives the gated gradient for the
+ *            weight-gradient launch.  MMF_EPI_MASK_AUX / alpha act on dx as in mmf_skinny_linear_dgrad. */
+typedef struct mmf_skinny_problem_ex {
+  mmf_skinny_problem p;
+  void* Y2;
+  const void* gate;
+  void* dz;
+  int32_t ldy2, ldgate, lddz, reserved;
+} mmf_skinny_problem_ex;
+typedef struct mmf_skinny_extra {
+  int32_t x_f32;        /* X (forward) / dY (dgrad) is f32 */
+  int32_t gate_f32;     /* the gate tensor is f32 */
+  float gate_scale;
+  float dropout_p;
+  const uint64_t* rng_state;
+  uint32_t site;
+  uint32_t reserved;
+} mmf_skinny_extra;
+int mmf_skinny_linear_fwd_ex(const mmf_skinny_problem_ex* problems, int num_problems, int flags, int out_f32,
+                             const mmf_skinny_extra* extra, void* stream);
+int mmf_skinny_linear_dgrad_ex(const mmf_skinny_problem_ex* problems, int num_problems, int flags, float alpha, int out_f32,
+                               const mmf_skinny_extra* extra, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Grouped fused attention (flash-style: no (Tq,Tk) score matrix in HBM).

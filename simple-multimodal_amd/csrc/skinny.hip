@@ -23,11 +23,43 @@ constexpr int MAX_MT = 4;                  // up to 64 rows
 
 struct SkinnyArgs {
   int nprob;
-  int flags;                               // MMF_EPI_BIAS | MMF_EPI_RELU | MMF_EPI_MASK_AUX
+  int flags;                               // MMF_EPI_BIAS | MMF_EPI_RELU | MMF_EPI_MASK_AUX | MMF_EPI_DROPOUT
   float alpha;
+  // round 4 (mmf_skinny_linear_*_ex): the casts, dropout and ReLU-gradient launches around a (B, d)-row linear folded into it
+  int x_f32;                               // X (forward) / dY (dgrad) is f32: narrowed while the fragment is loaded
+  int gate_f32;                            // dgrad: the gate tensor is f32
+  float gate_scale;                        // dgrad: dz = dy * (gate > 0) * gate_scale
+  unsigned drop_thresh, site;              // MMF_EPI_DROPOUT: forward y = dropout(act(.)); dgrad dz = dy * keep / (1 - p)
+  float drop_scale;
+  const unsigned long long* rng_state;
   int blk_start[MMF_SKINNY_MAX_PROBLEMS + 1];
   mmf_skinny_problem p[MMF_SKINNY_MAX_PROBLEMS];
+  void* y2[MMF_SKINNY_MAX_PROBLEMS];       // forward: second copy of the output in the other dtype, or null
+  const void* gate[MMF_SKINNY_MAX_PROBLEMS];   // dgrad: the forward's saved output [M][N], or null
+  void* dz[MMF_SKINNY_MAX_PROBLEMS];       // dgrad: the gated gradient as bf16 (the weight gradient's operand), or null;
+                                           // forward with an f32 X: the narrowed input as bf16 [M][lddz] (the same operand's other side)
+  int ldy2[MMF_SKINNY_MAX_PROBLEMS], ldgate[MMF_SKINNY_MAX_PROBLEMS], lddz[MMF_SKINNY_MAX_PROBLEMS];
 };
+
+// eight consecutive elements of row `row` at column `col` of a bf16 or f32 [rows][ld] matrix as f32 (zeros outside)
+__device__ __forceinline__ void load8_f32(const void* base, bool f32, int ld, int row, int rows, int col, int cols, float (&v)[8]) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = 0.f;
+  if (row >= rows || col >= cols) return;
+  if (f32) {
+    const float* p = static_cast<const float*>(base) + (size_t)row * ld + col;
+    const f32x4_t a = *reinterpret_cast<const f32x4_t*>(p), b = *reinterpret_cast<const f32x4_t*>(p + 4);
+    v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+  } else {
+    const u32x4_t w = *reinterpret_cast<const u32x4_t*>(static_cast<const unsigned short*>(base) + (size_t)row * ld + col);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[2 * e] = bf16lo(w[e]); v[2 * e + 1] = bf16hi(w[e]); }
+  }
+}
+__device__ __forceinline__ bf16x8_t pack8(const float (&v)[8]) {
+  const u32x4_t w = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+  return __builtin_bit_cast(bf16x8_t, w);
+}
 
 __device__ __forceinline__ bf16x8_t load_frag_rows(const unsigned short* __restrict__ base, int ld, int row, int rows,
                                                    int col, int cols) {
@@ -50,6 +82,7 @@ void skinny_fwd_kernel(const SkinnyArgs a) {
   const int mt = (M + 15) >> 4;
   const unsigned short* __restrict__ X = static_cast<const unsigned short*>(P.X);
   const unsigned short* __restrict__ W = static_cast<const unsigned short*>(P.W);
+  unsigned short* x16 = static_cast<unsigned short*>(a.dz[pi]);
 
   // this wave's share of K, in whole 32-element MFMA steps; the next step's fragments are requested
   // before the current step's MFMAs (the chain is otherwise one HBM/L2 latency per step)
@@ -65,7 +98,18 @@ void skinny_fwd_kernel(const SkinnyArgs a) {
     w = load_frag_rows(W, P.ldw, wrow, N, k, K);
 #pragma unroll
     for (int t = 0; t < MAX_MT; ++t)
-      if (t < mt) x[t] = load_frag_rows(X, P.ldx, t * 16 + (lane & 15), M, k, K);
+      if (t < mt) {
+        if (a.x_f32) {
+          float v[8];
+          const int m = t * 16 + (lane & 15);
+          load8_f32(P.X, true, P.ldx, m, M, k, K, v);
+          x[t] = pack8(v);
+          if (x16 && n0 == 0 && m < M && k < K)              // the first strip's workgroup leaves the bf16 copy behind (wgrad operand)
+            *reinterpret_cast<u32x4_t*>(x16 + (size_t)m * a.lddz[pi] + k) = __builtin_bit_cast(u32x4_t, x[t]);
+        } else {
+          x[t] = load_frag_rows(X, P.ldx, t * 16 + (lane & 15), M, k, K);
+        }
+      }
   };
   if (s0 < s1) fetch(s0, wf, xf);
   for (int s = s0; s < s1; ++s) {
@@ -97,11 +141,18 @@ void skinny_fwd_kernel(const SkinnyArgs a) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
         }
+        if (a.flags & MMF_EPI_DROPOUT) {
+          const unsigned key = mmf_rng_key(*a.rng_state, a.site, (unsigned)pi), idx = (unsigned)m * (unsigned)N + (unsigned)n;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = mmf_keep(key, idx + e, a.drop_thresh) ? v[e] * a.drop_scale : 0.f;
+        }
+        const u32x2_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
         if (OUT_F32) {
           *reinterpret_cast<f32x4_t*>(static_cast<float*>(P.Y) + (size_t)m * P.ldy + n) = v;
+          if (a.y2[pi]) *reinterpret_cast<u32x2_t*>(static_cast<unsigned short*>(a.y2[pi]) + (size_t)m * a.ldy2[pi] + n) = o;
         } else {
-          const u32x2_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
           *reinterpret_cast<u32x2_t*>(static_cast<unsigned short*>(P.Y) + (size_t)m * P.ldy + n) = o;
+          if (a.y2[pi]) *reinterpret_cast<f32x4_t*>(static_cast<float*>(a.y2[pi]) + (size_t)m * a.ldy2[pi] + n) = v;
         }
       }
     }
@@ -132,6 +183,10 @@ void skinny_dgrad_kernel(const SkinnyArgs a) {
   const unsigned short* __restrict__ dY = static_cast<const unsigned short*>(P.X);
   const unsigned short* __restrict__ W = static_cast<const unsigned short*>(P.W);
   char* slice = smem + wave * 32 * SB;
+  const void* gate = a.gate[pi];
+  unsigned short* dz = static_cast<unsigned short*>(a.dz[pi]);
+  const bool gated = a.x_f32 || gate || dz || (a.flags & MMF_EPI_DROPOUT);
+  const unsigned drop_key = (a.flags & MMF_EPI_DROPOUT) ? mmf_rng_key(*a.rng_state, a.site, (unsigned)pi) : 0u;
 
   const int steps = (Nout + 31) >> 5, per = (steps + SK_WAVES - 1) / SK_WAVES;
   const int s0 = wave * per, s1 = min(steps, s0 + per);
@@ -154,7 +209,30 @@ void skinny_dgrad_kernel(const SkinnyArgs a) {
     }
 #pragma unroll
     for (int t = 0; t < MAX_MT; ++t)
-      if (t < mt) y[t] = load_frag_rows(dY, P.ldx, t * 16 + (lane & 15), M, r0 + (g << 3), Nout);
+      if (t < mt) {
+        const int m = t * 16 + (lane & 15), n = r0 + (g << 3);
+        if (!gated) {
+          y[t] = load_frag_rows(dY, P.ldx, m, M, n, Nout);
+        } else {
+          // dz = dy * (gate > 0) * gate_scale [* keep / (1 - p)], narrowed to bf16: the ReLU / dropout gradient and the casts
+          // around it happen while the fragment is loaded; the first strip's workgroup also writes dz out (wgrad operand)
+          float v[8], gt[8];
+          load8_f32(P.X, a.x_f32 != 0, P.ldx, m, M, n, Nout, v);
+          if (gate) {
+            load8_f32(gate, a.gate_f32 != 0, a.ldgate[pi], m, M, n, Nout, gt);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = gt[e] > 0.f ? v[e] * a.gate_scale : 0.f;
+          }
+          if (a.flags & MMF_EPI_DROPOUT) {
+            const unsigned idx = (unsigned)m * (unsigned)Nout + (unsigned)n;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = mmf_keep(drop_key, idx + e, a.drop_thresh) ? v[e] * a.drop_scale : 0.f;
+          }
+          y[t] = pack8(v);
+          if (dz && c0 == 0 && m < M && n < Nout)
+            *reinterpret_cast<u32x4_t*>(dz + (size_t)m * a.lddz[pi] + n) = __builtin_bit_cast(u32x4_t, y[t]);
+        }
+      }
   };
   if (s0 < s1) fetch(s0, yf);
   for (int s = s0; s < s1; ++s) {
@@ -219,14 +297,14 @@ void skinny_dgrad_kernel(const SkinnyArgs a) {
   }
 }
 
-int check(const char* who, const mmf_skinny_problem* p, int n, int flags, bool dgrad) {
+int check(const char* who, const mmf_skinny_problem* p, int n, int flags, bool dgrad, bool x_f32) {
   if (!p || n <= 0 || n > MMF_SKINNY_MAX_PROBLEMS) MMF_FAIL(MMF_E_SHAPE, "%s: num_problems=%d out of range", who, n);
   for (int i = 0; i < n; ++i) {
     const mmf_skinny_problem& q = p[i];
     if (q.M <= 0 || q.M > 16 * MAX_MT || q.N <= 0 || q.K <= 0)
       MMF_FAIL(MMF_E_SHAPE, "%s[%d]: M=%d (1..%d) N=%d K=%d", who, i, q.M, 16 * MAX_MT, q.N, q.K);
     const int out_cols = dgrad ? q.K : q.N, red = dgrad ? q.N : q.K;
-    if ((red & 7) || (q.ldx & 7) || (q.ldw & 7) || (out_cols & 3) || (q.ldy & 3) || (dgrad && (q.K & 7)))
+    if ((red & 7) || (q.ldx & (x_f32 ? 3 : 7)) || (q.ldw & 7) || (out_cols & 3) || (q.ldy & 3) || (dgrad && (q.K & 7)))
       MMF_FAIL(MMF_E_ALIGN, "%s[%d]: reduction extent / leading dimensions must be multiples of 8, outputs of 4", who, i);
     if (!q.X || !q.W || !q.Y || !mmf_aligned16(q.X) || !mmf_aligned16(q.W) || !mmf_aligned16(q.Y))
       MMF_FAIL(MMF_E_ALIGN, "%s[%d]: null or unaligned operand", who, i);
@@ -236,12 +314,38 @@ int check(const char* who, const mmf_skinny_problem* p, int n, int flags, bool d
   return MMF_OK;
 }
 
-}  // namespace
+// fills the round-4 fields of the kernel arguments from the extended problem table (or clears them)
+int fill_ex(const char* who, SkinnyArgs& a, const mmf_skinny_problem_ex* px, int n, const mmf_skinny_extra* ex, bool dgrad) {
+  a.x_f32 = ex ? ex->x_f32 : 0;
+  a.gate_f32 = ex ? ex->gate_f32 : 0;
+  a.gate_scale = ex ? ex->gate_scale : 1.f;
+  a.rng_state = ex ? reinterpret_cast<const unsigned long long*>(ex->rng_state) : nullptr;
+  a.site = ex ? ex->site : 0u;
+  a.drop_thresh = 0u; a.drop_scale = 1.f;
+  if (a.flags & MMF_EPI_DROPOUT) {
+    if (!ex || !ex->rng_state || !(ex->dropout_p >= 0.f) || ex->dropout_p >= 1.f)
+      MMF_FAIL(MMF_E_SHAPE, "%s: MMF_EPI_DROPOUT needs rng_state and 0 <= p < 1", who);
+    a.drop_thresh = mmf_drop_thresh(ex->dropout_p);
+    a.drop_scale = 1.f / (1.f - (float)a.drop_thresh * (1.f / 4294967296.f));
+  }
+  for (int i = 0; i < n; ++i) {
+    a.y2[i] = px ? px[i].Y2 : nullptr; a.ldy2[i] = px ? px[i].ldy2 : 0;
+    a.gate[i] = px ? px[i].gate : nullptr; a.ldgate[i] = px ? px[i].ldgate : 0;
+    a.dz[i] = px ? px[i].dz : nullptr; a.lddz[i] = px ? px[i].lddz : 0;
+    if (!px) continue;
+    const mmf_skinny_problem& q = px[i].p;
+    if (a.x_f32 && (q.ldx & 3)) MMF_FAIL(MMF_E_ALIGN, "%s[%d]: f32 input rows must keep 16-byte alignment (ldx %% 4)", who, i);
+    if (!dgrad && a.y2[i] && (!mmf_aligned16(a.y2[i]) || (a.ldy2[i] & 3) || a.ldy2[i] < q.N))
+      MMF_FAIL(MMF_E_ALIGN, "%s[%d]: second output", who, i);
+    if (dgrad && a.gate[i] && (!mmf_aligned16(a.gate[i]) || (a.ldgate[i] & (a.gate_f32 ? 3 : 7)) || a.ldgate[i] < q.N))
+      MMF_FAIL(MMF_E_ALIGN, "%s[%d]: gate", who, i);
+    if (a.dz[i] && (!mmf_aligned16(a.dz[i]) || (a.lddz[i] & 7) || a.lddz[i] < (dgrad ? q.N : q.K)))
+      MMF_FAIL(MMF_E_ALIGN, "%s[%d]: dz", who, i);
+  }
+  return MMF_OK;
+}
 
-extern "C" int mmf_skinny_linear_fwd(const mmf_skinny_problem* problems, int num_problems, int flags, int out_f32,
-                                     void* stream) {
-  if (int rc = check("mmf_skinny_linear_fwd", problems, num_problems, flags, false)) return rc;
-  SkinnyArgs a; a.nprob = num_problems; a.flags = flags; a.alpha = 1.f;
+int launch_fwd(SkinnyArgs& a, const mmf_skinny_problem* problems, int num_problems, int out_f32, void* stream) {
   int total = 0;
   for (int i = 0; i < num_problems; ++i) { a.blk_start[i] = total; total += (problems[i].N + 15) / 16; a.p[i] = problems[i]; }
   a.blk_start[num_problems] = total;
@@ -252,10 +356,7 @@ extern "C" int mmf_skinny_linear_fwd(const mmf_skinny_problem* problems, int num
   return MMF_OK;
 }
 
-extern "C" int mmf_skinny_linear_dgrad(const mmf_skinny_problem* problems, int num_problems, int flags, float alpha,
-                                       int out_f32, void* stream) {
-  if (int rc = check("mmf_skinny_linear_dgrad", problems, num_problems, flags, true)) return rc;
-  SkinnyArgs a; a.nprob = num_problems; a.flags = flags; a.alpha = alpha;
+int launch_dgrad(SkinnyArgs& a, const mmf_skinny_problem* problems, int num_problems, int out_f32, void* stream) {
   int wide = 0;
   for (int i = 0; i < num_problems; ++i) wide += (problems[i].K + 63) / 64;
   // strip width: 64 columns when that already gives the chip a workgroup per two CUs, else 32, else 16 (MMF_SKINNY_CT pins it)
@@ -276,4 +377,48 @@ extern "C" int mmf_skinny_linear_dgrad(const mmf_skinny_problem* problems, int n
   }
   MMF_CHECK_LAUNCH("mmf_skinny_linear_dgrad");
   return MMF_OK;
+}
+
+}  // namespace
+
+extern "C" int mmf_skinny_linear_fwd(const mmf_skinny_problem* problems, int num_problems, int flags, int out_f32,
+                                     void* stream) {
+  if (int rc = check("mmf_skinny_linear_fwd", problems, num_problems, flags & ~MMF_EPI_DROPOUT, false, false)) return rc;
+  if (flags & MMF_EPI_DROPOUT) MMF_FAIL(MMF_E_UNSUPPORTED, "mmf_skinny_linear_fwd: dropout needs mmf_skinny_linear_fwd_ex");
+  SkinnyArgs a; a.nprob = num_problems; a.flags = flags; a.alpha = 1.f;
+  if (int rc = fill_ex("mmf_skinny_linear_fwd", a, nullptr, num_problems, nullptr, false)) return rc;
+  return launch_fwd(a, problems, num_problems, out_f32, stream);
+}
+
+extern "C" int mmf_skinny_linear_dgrad(const mmf_skinny_problem* problems, int num_problems, int flags, float alpha,
+                                       int out_f32, void* stream) {
+  if (int rc = check("mmf_skinny_linear_dgrad", problems, num_problems, flags & ~MMF_EPI_DROPOUT, true, false)) return rc;
+  if (flags & MMF_EPI_DROPOUT) MMF_FAIL(MMF_E_UNSUPPORTED, "mmf_skinny_linear_dgrad: dropout needs mmf_skinny_linear_dgrad_ex");
+  SkinnyArgs a; a.nprob = num_problems; a.flags = flags; a.alpha = alpha;
+  if (int rc = fill_ex("mmf_skinny_linear_dgrad", a, nullptr, num_problems, nullptr, true)) return rc;
+  return launch_dgrad(a, problems, num_problems, out_f32, stream);
+}
+
+extern "C" int mmf_skinny_linear_fwd_ex(const mmf_skinny_problem_ex* problems, int num_problems, int flags, int out_f32,
+                                        const mmf_skinny_extra* extra, void* stream) {
+  if (!problems || num_problems <= 0 || num_problems > MMF_SKINNY_MAX_PROBLEMS)
+    MMF_FAIL(MMF_E_SHAPE, "mmf_skinny_linear_fwd_ex: num_problems=%d out of range", num_problems);
+  mmf_skinny_problem plain[MMF_SKINNY_MAX_PROBLEMS];
+  for (int i = 0; i < num_problems; ++i) plain[i] = problems[i].p;
+  if (int rc = check("mmf_skinny_linear_fwd_ex", plain, num_problems, flags & ~MMF_EPI_DROPOUT, false, extra && extra->x_f32)) return rc;
+  SkinnyArgs a; a.nprob = num_problems; a.flags = flags; a.alpha = 1.f;
+  if (int rc = fill_ex("mmf_skinny_linear_fwd_ex", a, problems, num_problems, extra, false)) return rc;
+  return launch_fwd(a, plain, num_problems, out_f32, stream);
+}
+
+extern "C" int mmf_skinny_linear_dgrad_ex(const mmf_skinny_problem_ex* problems, int num_problems, int flags, float alpha,
+                                          int out_f32, const mmf_skinny_extra* extra, void* stream) {
+  if (!problems || num_problems <= 0 || num_problems > MMF_SKINNY_MAX_PROBLEMS)
+    MMF_FAIL(MMF_E_SHAPE, "mmf_skinny_linear_dgrad_ex: num_problems=%d out of range", num_problems);
+  mmf_skinny_problem plain[MMF_SKINNY_MAX_PROBLEMS];
+  for (int i = 0; i < num_problems; ++i) plain[i] = problems[i].p;
+  if (int rc = check("mmf_skinny_linear_dgrad_ex", plain, num_problems, flags & ~MMF_EPI_DROPOUT, true, extra && extra->x_f32)) return rc;
+  SkinnyArgs a; a.nprob = num_problems; a.flags = flags; a.alpha = alpha;
+  if (int rc = fill_ex("mmf_skinny_linear_dgrad_ex", a, problems, num_problems, extra, true)) return rc;
+  return launch_dgrad(a, plain, num_problems, out_f32, stream);
 }

@@ -26,7 +26,7 @@ SYMBOLS = (
     "mmf_attn_fwd_grouped", "mmf_attn_bwd_grouped", "mmf_layernorm_fwd_grouped",
     "mmf_layernorm_bwd_grouped", "mmf_layernorm_bwd_workspace_bytes", "mmf_cast_f32_to_bf16", "mmf_cast_bf16_to_f32", "mmf_cast_bf16_to_f32_scaled", "mmf_cast_f32_to_bf16_2d", "mmf_add3_bf16", "mmf_add3_grouped", "mmf_addn_bf16", "mmf_addn_grouped",
     "mmf_meanpool_fwd", "mmf_meanpool_bwd", "mmf_meanpool_cat_fwd", "mmf_meanpool_cat_bwd", "mmf_colsum_bf16", "mmf_colsum_grouped", "mmf_relu_bwd_bf16", "mmf_relu_bwd_mixed",
-    "mmf_sqnorm_f32", "mmf_adamw_step", "mmf_adamw_advance", "mmf_skinny_linear_fwd", "mmf_skinny_linear_dgrad",
+    "mmf_sqnorm_f32", "mmf_adamw_step", "mmf_adamw_advance", "mmf_skinny_linear_fwd", "mmf_skinny_linear_dgrad", "mmf_skinny_linear_fwd_ex", "mmf_skinny_linear_dgrad_ex",
     "mmf_gat3_dense_fwd", "mmf_gat3_dense_bwd", "mmf_infonce_fwd", "mmf_infonce_bwd", "mmf_adaptive_combine_fwd",
     "mmf_adaptive_combine_bwd", "mmf_adaptive_attn_weights", "mmf_linear_narrow_fwd", "mmf_linear_narrow_bwd", "mmf_stack3_embed_fwd",
     "mmf_stack3_embed_bwd", "mmf_rowmask_apply", "mmf_zero_ranges_f32",
@@ -63,6 +63,16 @@ class SkinnyProblem(C.Structure):
     _fields_ = [("X", C.c_void_p), ("W", C.c_void_p), ("Y", C.c_void_p), ("bias", C.c_void_p), ("aux", C.c_void_p),
                 ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("ldx", C.c_int32), ("ldw", C.c_int32),
                 ("ldy", C.c_int32), ("ldaux", C.c_int32)]
+
+
+class SkinnyProblemEx(C.Structure):
+    _fields_ = [("p", SkinnyProblem), ("Y2", C.c_void_p), ("gate", C.c_void_p), ("dz", C.c_void_p),
+                ("ldy2", C.c_int32), ("ldgate", C.c_int32), ("lddz", C.c_int32), ("reserved", C.c_int32)]
+
+
+class SkinnyExtra(C.Structure):
+    _fields_ = [("x_f32", C.c_int32), ("gate_f32", C.c_int32), ("gate_scale", C.c_float), ("dropout_p", C.c_float),
+                ("rng_state", C.c_void_p), ("site", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 SKINNY_MAX_M, SKINNY_MAX_PROBLEMS = 64, 24
@@ -146,6 +156,8 @@ def load() -> C.CDLL:
     lib.mmf_relu_bwd_mixed.argtypes = [vp, C.c_int, vp, C.c_int, vp, i64, vp]
     lib.mmf_skinny_linear_fwd.argtypes = [C.POINTER(SkinnyProblem), i32, i32, i32, vp]
     lib.mmf_skinny_linear_dgrad.argtypes = [C.POINTER(SkinnyProblem), i32, i32, f32, i32, vp]
+    lib.mmf_skinny_linear_fwd_ex.argtypes = [C.POINTER(SkinnyProblemEx), i32, i32, i32, C.POINTER(SkinnyExtra), vp]
+    lib.mmf_skinny_linear_dgrad_ex.argtypes = [C.POINTER(SkinnyProblemEx), i32, i32, f32, i32, C.POINTER(SkinnyExtra), vp]
     lib.mmf_sqnorm_f32.argtypes = [vp, i64, vp, vp]
     P3 = C.c_void_p * 3
     lib.mmf_gat3_dense_fwd.argtypes = [vp] * 8 + [C.POINTER(Gat3Params), vp]
@@ -280,6 +292,21 @@ def skinny_fwd(problems: Sequence[SkinnyProblem], flags: int, out_f32: bool) -> 
         chunk = problems[i:i + SKINNY_MAX_PROBLEMS]
         arr = (SkinnyProblem * len(chunk))(*chunk)
         check(load().mmf_skinny_linear_fwd(arr, len(chunk), flags, int(out_f32), stream_ptr()))
+
+
+def skinny_fwd_ex(problems: Sequence[SkinnyProblemEx], flags: int, out_f32: bool, extra: SkinnyExtra) -> None:
+    """one launch: the group must fit (a dropout group's problem index keys its masks)"""
+    if len(problems) > SKINNY_MAX_PROBLEMS:
+        raise ValueError("a fused row-linear group must fit one launch")
+    arr = (SkinnyProblemEx * len(problems))(*problems)
+    check(load().mmf_skinny_linear_fwd_ex(arr, len(problems), flags, int(out_f32), C.byref(extra), stream_ptr()))
+
+
+def skinny_dgrad_ex(problems: Sequence[SkinnyProblemEx], flags: int, alpha: float, out_f32: bool, extra: SkinnyExtra) -> None:
+    if len(problems) > SKINNY_MAX_PROBLEMS:
+        raise ValueError("a fused row-linear group must fit one launch")
+    arr = (SkinnyProblemEx * len(problems))(*problems)
+    check(load().mmf_skinny_linear_dgrad_ex(arr, len(problems), flags, alpha, int(out_f32), C.byref(extra), stream_ptr()))
 
 
 def skinny_dgrad(problems: Sequence[SkinnyProblem], flags: int, alpha: float, out_f32: bool) -> None:

@@ -737,24 +737,169 @@ class _GroupedLinear(torch.autograd.Function):
         return (None, None, *grads)
 
 
-def linear_group(items: Sequence[tuple], out_f32: bool = False, cat: bool = False):
+def _rows2d(t: torch.Tensor) -> torch.Tensor:
+    """2-D, last dimension contiguous (row-strided views — column blocks of a wider tensor — pass as they are)"""
+    if t.dim() != 2:
+        raise ValueError(f"expected a 2-D tensor, got {tuple(t.shape)}")
+    return t if t.stride(1) == 1 else t.contiguous()
+
+
+class _RowLinear(torch.autograd.Function):
+    """(B, d)-row linears — M <= 64 rows: the Early / Contrastive / Adaptive / Graph / meta / classifier MLPs and the encoder
+    projection tails — with the launches AROUND them folded in (round 4; mmf_skinny_linear_*_ex).  At these sizes a launch costs
+    ~5 us and the arithmetic nothing: a Linear + ReLU + Dropout fed by an f32 tensor was cast, linear, dropout (3 launches)
+    forward and dropout, ReLU mask, (cast), dgrad (3-4) backward; here it is one launch each way:
+      forward   y = dropout(act(x W^T + b)): x may be f32 (narrowed while loaded; the bf16 copy the weight gradient needs is
+                written by the kernel's first workgroup), the dropout mask is drawn in the epilogue, and with ``dual`` a second
+                copy of y in the other dtype comes out of the same launch (the bf16 operand of the next linear beside the f32
+                value the module returns);
+      backward  dz = g * (y > 0) / (1 - p) — a ReLU + dropout output is exactly 0 where either gate is closed — or, for dropout
+                without ReLU, the regenerated mask, is formed while the dgrad kernel loads g (bf16 or f32, row-strided views
+                welcome); dz (bf16) is written once for the deferred weight-gradient launch.
+    tensors = [x_0, w_0.p, b_0.p | None, x_1, ...]; returns the n outputs (+ n second copies with ``dual``)."""
+
+    @staticmethod
+    def forward(ctx, specs: List[LinearSpec], opts, *tensors):
+        out_f32, p, dual = opts
+        n = len(specs)
+        relu, has_bias = specs[0].relu, specs[0].b is not None
+        if any(s.relu != relu or (s.b is not None) != has_bias or s.has_residual for s in specs):
+            raise ValueError("a row-linear group must share one epilogue and has no residual form")
+        xs = [_rows2d(tensors[3 * i]) for i in range(n)]
+        f32_in = xs[0].dtype == torch.float32
+        for x in xs:
+            if not x.is_cuda:
+                raise RuntimeError("mmfusion ops run on the GPU only (no CPU fallback)")
+            if x.dtype not in (BF16, torch.float32) or (x.dtype == torch.float32) != f32_in:
+                raise TypeError("a row-linear group's inputs must share one dtype (bf16 or f32)")
+        site = next_site() if p > 0.0 else 0
+        probs, outs, outs2, x16s = [], [], [], []
+        for i, s in enumerate(specs):
+            x, w16 = xs[i], s.w.w16
+            M, K, N = x.shape[0], x.shape[1], w16.shape[0]
+            y = torch.empty((M, N), dtype=torch.float32 if out_f32 else BF16, device=x.device)
+            y2 = torch.empty((M, N), dtype=BF16 if out_f32 else torch.float32, device=x.device) if dual else None
+            x16 = torch.empty((M, K), dtype=BF16, device=x.device) if f32_in else x
+            bias = s.b.master if has_bias else None
+            probs.append(lib.SkinnyProblemEx(
+                lib.SkinnyProblem(x.data_ptr(), w16.data_ptr(), y.data_ptr(), bias.data_ptr() if bias is not None else None, None,
+                                  M, N, K, _ld(x), _ld(w16), _ld(y), 0),
+                y2.data_ptr() if y2 is not None else None, None, x16.data_ptr() if f32_in else None,
+                _ld(y2) if y2 is not None else 0, 0, _ld(x16) if f32_in else 0, 0))
+            outs.append(y), outs2.append(y2), x16s.append(x16)
+        flags = (EPI_BIAS if has_bias else 0) | (EPI_RELU if relu else 0) | (EPI_DROPOUT if p > 0.0 else 0)
+        extra = lib.SkinnyExtra(int(f32_in), 0, 1.0, float(p), rng_state().data_ptr() if p > 0.0 else None, site, 0)
+        lib.skinny_fwd_ex(probs, flags, out_f32, extra)
+        ctx.specs, ctx.opts, ctx.site, ctx.f32_in = specs, opts, site, f32_in
+        ctx.save_for_backward(*x16s, *(outs if relu else []))
+        ctx.x_needs = [tensors[3 * i].requires_grad for i in range(n)]
+        return tuple(outs) + (tuple(outs2) if dual else ())
+
+    @staticmethod
+    def backward(ctx, *gs):
+        specs = ctx.specs
+        out_f32, p, dual = ctx.opts
+        n = len(specs)
+        relu, has_bias = specs[0].relu, specs[0].b is not None
+        saved = ctx.saved_tensors
+        x16s, ys = saved[:n], (saved[n:] if relu else [None] * n)
+        grads: List[Optional[torch.Tensor]] = [None] * (3 * n)
+        todo = []
+        for i in range(n):
+            g, g2 = gs[i], (gs[n + i] if dual else None)
+            if g is not None and g2 is not None:             # both copies of the output were used downstream
+                g = g.float() + g2.float()
+            elif g is None:
+                g = g2
+            if g is not None:
+                g = _rows2d(g)
+                if g.data_ptr() % 16 or g.stride(0) % (4 if g.dtype == torch.float32 else 8):
+                    g = g.contiguous()                       # (a view whose rows lose the 16-byte alignment of the vector loads)
+                todo.append((i, g))
+        # one launch per gradient dtype (the kernel narrows f32 gradients itself)
+        for want_f32 in (False, True):
+            grp = [(i, g) for i, g in todo if (g.dtype == torch.float32) == want_f32]
+            if not grp:
+                continue
+            gated = relu or p > 0.0
+            probs, dxs = [], []
+            for i, g in grp:
+                w16 = specs[i].w.w16
+                M, N, K = g.shape[0], w16.shape[0], w16.shape[1]
+                if g.dtype not in (BF16, torch.float32):
+                    raise TypeError("row-linear backward: bf16 or f32 gradients only")
+                dz = torch.empty((M, N), dtype=BF16, device=g.device) if (gated or want_f32) else g
+                dx = torch.empty((M, K), dtype=torch.float32 if ctx.f32_in else BF16, device=g.device)
+                y = ys[i]
+                probs.append(lib.SkinnyProblemEx(
+                    lib.SkinnyProblem(g.data_ptr(), w16.data_ptr(), dx.data_ptr(), None, None, M, N, K, _ld(g), _ld(w16), _ld(dx), 0),
+                    None, y.data_ptr() if y is not None else None, dz.data_ptr() if dz is not g else None,
+                    0, _ld(y) if y is not None else 0, _ld(dz) if dz is not g else 0, 0))
+                dxs.append(dx)
+                queue_wgrad(dz, x16s[i], specs[i].w.grad, specs[i].b.grad if has_bias else None)
+                if ctx.x_needs[i]:
+                    grads[3 * i] = dx
+            regen = p > 0.0 and not relu                      # dropout without ReLU: the mask is drawn again from (state, site)
+            extra = lib.SkinnyExtra(int(want_f32), int(relu and ys[grp[0][0]].dtype == torch.float32),
+                                    1.0 / (1.0 - p) if (relu and p > 0.0) else 1.0, float(p) if regen else 0.0,
+                                    rng_state().data_ptr() if regen else None, ctx.site, 0)
+            lib.skinny_dgrad_ex(probs, EPI_DROPOUT if regen else 0, 1.0, ctx.f32_in, extra)
+        return (None, None, *grads)
+
+
+def row_linear_ok(items: Sequence[tuple]) -> bool:
+    """whether a linear group can take the fused (B, d)-row form: bf16 mode, <= 64 rows, no residual, one launch"""
+    if _PRECISION == "fp32" or not _SKINNY or len(items) > lib.SKINNY_MAX_PROBLEMS:
+        return False
+    for x, spec, res in items:
+        if res is not None or x.dim() != 2 or x.shape[0] > lib.SKINNY_MAX_M or x.shape[1] % 8 or spec.w.w16.shape[0] % 4:
+            return False
+        if x.dtype == torch.float32 and (x.stride(1) != 1 or x.stride(0) % 4 or x.data_ptr() % 16):
+            return False
+        if x.dtype == BF16 and (x.stride(1) != 1 or x.stride(0) % 8 or x.data_ptr() % 16):
+            return False
+    return True
+
+
+def linear_group(items: Sequence[tuple], out_f32: bool = False, cat: bool = False, dropout_p: float = 0.0, dual: bool = False):
     """items: (x_bf16 [M,K], LinearSpec, residual_bf16|None).  One NT launch for the group.  Returns the list of
     outputs, or with ``cat`` ONE (M, sum N_i) tensor whose column blocks are the outputs (equal M required)."""
+    """``dropout_p``: nn.Dropout(p) on every output (training-mode probability: pass 0 in eval).  ``dual``: every output also as
+    a second tensor in the OTHER dtype — the return value is then a list of (y, y_other) pairs.  Groups of (B, d)-row problems
+    (``row_linear_ok``) run both inside the linear's own launch (``_RowLinear``); otherwise they are separate kernels."""
     if _PRECISION == "fp32":
-        return _f32().linear_group(items, cat)
+        ys = _f32().linear_group(items, cat)
+        if dropout_p > 0.0:
+            raise RuntimeError("the fp32 parity mode runs without dropout (use p = 0 or eval())")
+        return [(y, y) for y in ys] if dual else ys
+    if not cat and row_linear_ok(items):
+        specs, tensors = [], []
+        for x, spec, res in items:
+            spec.has_residual = False
+            specs.append(spec)
+            tensors += [x, spec.w.p, spec.b.p if spec.b is not None else None]
+        outs = _RowLinear.apply(specs, (bool(out_f32), float(dropout_p), bool(dual)), *tensors)
+        n = len(specs)
+        return [(outs[i], outs[n + i]) for i in range(n)] if dual else list(outs)
     specs, tensors = [], []
     for x, spec, res in items:
         spec.has_residual = res is not None
         specs.append(spec)
         tensors += [x, res, spec.w.p, spec.b.p if spec.b is not None else None]
     if cat:
-        return _GroupedLinear.apply(specs, (out_f32, True), *tensors)
-    return list(_GroupedLinear.apply(specs, out_f32, *tensors))
+        ys = _GroupedLinear.apply(specs, (out_f32, True), *tensors)
+        if dropout_p > 0.0 or dual:
+            raise ValueError("a concatenated linear group has no dropout / dual form")
+        return ys
+    ys = [dropout(y, dropout_p, True) for y in _GroupedLinear.apply(specs, out_f32, *tensors)]
+    if dual:
+        return [(y, (to_bf16(y) if out_f32 else to_f32(y))) for y in ys]
+    return ys
 
 
 def linear(x: torch.Tensor, w: W, b: Optional[W] = None, relu: bool = False,
-           residual: Optional[torch.Tensor] = None, out_f32: bool = False) -> torch.Tensor:
-    return linear_group([(x, LinearSpec(w, b, relu), residual)], out_f32)[0]
+           residual: Optional[torch.Tensor] = None, out_f32: bool = False, dropout_p: float = 0.0, dual: bool = False):
+    return linear_group([(x, LinearSpec(w, b, relu), residual)], out_f32, dropout_p=dropout_p, dual=dual)[0]
 
 
 # --------------------------------------------------------------------------------------------

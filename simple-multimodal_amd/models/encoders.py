@@ -90,7 +90,7 @@ def _mha_mean_project(mha: _MHAParams, projection: nn.Linear, seq: torch.Tensor,
                               mha.num_heads, mha.head_dim, [qkv], dropout_p=p)[0]
     attended = ops.linear(att, *_wb(mha.out_proj))
     pooled = ops.meanpool_cat([attended.view(B, T, hdim)])
-    projected = ops.dropout(ops.linear(pooled, *_wb(projection), out_f32=True), p, True)     # reference :161 / :245
+    projected = ops.linear(pooled, *_wb(projection), out_f32=True, dropout_p=p)              # reference :161 / :245
     return projected, ops.to_f32(attended).view(B, T, hdim), weights
 
 
@@ -133,8 +133,8 @@ class TextEncoder(_FusionBase):
         else:                                                              # reference :90-94
             m = attention_mask.unsqueeze(-1).to(sequence_output.dtype)
             pooled = (sequence_output * m).sum(1) / m.sum(1).clamp_min(1e-9)
-        projected = ops.dropout(ops.linear(_as_rows(pooled), *_wb(self.projection), out_f32=True),
-                                _p(self, self.config.fusion_dropout), True)                  # reference :97-98
+        projected = ops.linear(_as_rows(pooled), *_wb(self.projection), out_f32=True,
+                               dropout_p=_p(self, self.config.fusion_dropout))               # reference :97-98
         return {"features": projected, "sequence_output": sequence_output, "attention_mask": attention_mask}
 
 

@@ -229,8 +229,8 @@ class EarlyFusion(_FusionBase):
     def forward(self, text_features, audio_features, video_features) -> torch.Tensor:
         p = _p(self, self.config.fusion_dropout)
         _, x = _cat3(text_features, audio_features, video_features)                    # bf16 (B, 3d), :36
-        h = ops.dropout(ops.linear(x, *_wb(self.fusion_layers[0]), relu=True), p, True)
-        return ops.dropout(ops.linear(h, *_wb(self.fusion_layers[3]), relu=True, out_f32=True), p, True)
+        h = ops.linear(x, *_wb(self.fusion_layers[0]), relu=True, dropout_p=p)
+        return ops.linear(h, *_wb(self.fusion_layers[3]), relu=True, out_f32=True, dropout_p=p)
 
 
 def _wb(layer: nn.Linear):
@@ -391,8 +391,7 @@ class MultimodalTransformer(_FusionBase):
         pooled_att = ops.meanpool_cat([att[0].view(B, Tt, d), att[1].view(B, Ta, d), att[2].view(B, Tv, d)])
         pf = ops.linear_group([(x, _lin(m.out_proj), None) for x, m in zip(sops.split3(pooled_att), mhas)],
                               out_f32=True, cat=True)                           # :171 (B, 3d) f32, written in place
-        fused = ops.dropout(ops.linear(pf, *_wb(self.final_fusion[0]), relu=True, out_f32=True),
-                            p, True)                                            # :172
+        fused = ops.linear(pf, *_wb(self.final_fusion[0]), relu=True, out_f32=True, dropout_p=p)      # :172
         return {"fused_features": fused, "text_features": pf[:, :d], "audio_features": pf[:, d:2 * d],
                 "video_features": pf[:, 2 * d:]}
 
@@ -499,7 +498,7 @@ class ContrastiveFusion(_FusionBase):
                 losses = {"text_audio": self.contrastive_loss(tp, ap),
                           "text_video": self.contrastive_loss(tp, vp),
                           "audio_video": self.contrastive_loss(ap, vp)}
-        fused = ops.dropout(ops.linear(cat, *_wb(self.fusion_layer[0]), relu=True, out_f32=True), p, True)
+        fused = ops.linear(cat, *_wb(self.fusion_layer[0]), relu=True, out_f32=True, dropout_p=p)
         return {"fused_features": fused, "text_proj": tp, "audio_proj": ap, "video_proj": vp,
                 "contrastive_losses": losses}
 
@@ -554,7 +553,7 @@ class AdaptiveFusion(_FusionBase):
             weighted = (attended * aw.unsqueeze(-1)).sum(dim=1)
         else:
             weighted, aw = sops.adaptive_combine(hp, attended, self.weight_predictor[2].weight, self.weight_predictor[2].bias)
-        fused = ops.dropout(ops.linear(weighted, *_wb(self.fusion_layer[0]), relu=True, out_f32=True), p, True)
+        fused = ops.linear(weighted, *_wb(self.fusion_layer[0]), relu=True, out_f32=True, dropout_p=p)
         return {"fused_features": fused, "attention_weights": attn_w, "adaptive_weights": aw}
 
 
@@ -619,9 +618,11 @@ class HierarchicalFusion(_FusionBase):
             for dct, key in ((mult, "mult_features"), (con, "contrastive_features"), (ada, "adaptive_features")):
                 if key in um:
                     dct["fused_features"] = dct["fused_features"] * um[key]
-        allf = _as_rows(torch.cat([early, mult["fused_features"], graph, con["fused_features"],
-                                   ada["fused_features"]], dim=-1))                    # :503-506
-        h = ops.dropout(ops.linear(allf, *_wb(self.meta_fusion[0]), relu=True), p, True)
+        allf = torch.cat([early, mult["fused_features"], graph, con["fused_features"],
+                          ada["fused_features"]], dim=-1)                             # :503-506, f32 (B, 5d): narrowed by the linear itself
+        if ops.fp32_mode():
+            allf = _as_rows(allf)
+        h = ops.linear(allf, *_wb(self.meta_fusion[0]), relu=True, dropout_p=p)
         if um:
             if "capture" in um:
                 um["capture"]["meta_hidden"] = h.detach()

@@ -54,9 +54,11 @@ class EmotionClassifier(nn.Module):
         if getattr(self.classifier[0].weight, "_mmf_arena", None) is None:
             _arena_mod.ensure(self)                # stand-alone use; inside MultimodalEmotionModel the root did it
         p = float(self.config.fusion_dropout) if self.training else 0.0
-        x = ops.to_bf16(features.float().contiguous())
+        x = features.float().contiguous()                  # f32 rows: narrowed by the linear itself (mmfusion.ops._RowLinear)
+        if ops.fp32_mode():
+            x = ops.to_bf16(x)
         l0 = self.classifier[0]
-        h = ops.dropout(ops.linear(x, W(l0.weight), W(l0.bias), relu=True, out_f32=True), p, True)
+        h = ops.linear(x, W(l0.weight), W(l0.bias), relu=True, out_f32=True, dropout_p=p)
         return sops.narrow_linear(h, self.classifier[3])
 
 
