@@ -150,7 +150,7 @@ def make_train_step(model, xs, arena, world, allreduce, rank, shard_optimizer=Fa
     """hierarchical-fusion TRAINING step (BASELINE configs[3]): zero grads, forward, CE(ls=0.1) + 0.1 *
     contrastive, backward | RCCL all-reduce | clip(1.0) + AdamW (fused, also refreshes the bf16 shadow)."""
     from mmfusion import dp
-    from mmfusion.train import FusedAdamW, fusion_loss, one_cycle_lr
+    from mmfusion.train import FusedAdamW, backward_from, fusion_loss, one_cycle_lr
     # --shard-optimizer (N > 1): ZeRO-1 step — reduce-scatter of the gradients, AdamW on this rank's 1/N of the arena,
     # all-gather of the bf16 shadow — instead of all-reduce + replicated AdamW (mmfusion.train.FusedAdamW.launch_sharded)
     opt = FusedAdamW(arena, lr=1e-4, weight_decay=1e-5, max_grad_norm=1.0, shard=shard_optimizer)
@@ -164,7 +164,7 @@ def make_train_step(model, xs, arena, world, allreduce, rank, shard_optimizer=Fa
         for x in xs:
             x.grad = None                # input gradients are produced anew each step, not accumulated across steps
         out = model(*xs, compute_contrastive_loss=True)
-        fusion_loss(out, labels).backward()
+        backward_from(fusion_loss(out, labels))
         arena.finalize_grads()
 
     def before_replay():                 # nothing crosses the host per step any more (pinned-buffer race)

@@ -178,6 +178,21 @@ int mmf_skinny_linear_dgrad_ex(const mmf_skinny_problem_ex* problems, int num_pr
                                const mmf_skinny_extra* extra, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Training-step loss and ModalityDropout as one launch each (round 4; csrc/loss.hip).
+ * mmf_fusion_loss: replaces the loss of training/advanced_trainer.py:139-166 —
+ *   loss = mean_b CE_ls(logits[b], targets[b]) + sum_j extra_w[j] * extra[j][0]
+ * with CE_ls = (1 - eps) * (-log p_y) + eps * (-(1 / C) sum_c log p_c) (torch's label_smoothing), C <= 64 — and writes
+ * dlogits[b][c] = d loss / d logits (f32 [B][C], may be NULL).  extra[j]: device scalars (the contrastive / distillation losses).
+ * mmf_modality_dropout: replaces models/encoders.py:289-321 — y_m[b] = x_m[b] * keep[b][m] for the three (B, d) f32 feature
+ * tensors; draw != 0: keep[b][m] ~ Bernoulli(1 - p) from the counter-based hash of (*rng_state, site, 3 b + m), a sample with no
+ * modality left gets one back, the masks are written to `keep` (f32 [B][3]); draw == 0: `keep` is applied as given (backward).
+ * ------------------------------------------------------------------------------------------ */
+int mmf_fusion_loss(const float* logits, int ldl, const int64_t* targets, int B, int C, float label_smoothing,
+                    const float* const* extra, const float* extra_w, int n_extra, float* loss, float* dlogits, void* stream);
+int mmf_modality_dropout(const float* const* x, float* const* y, float* keep, int B, int d, float p,
+                         const uint64_t* rng_state, uint32_t site, int draw, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Grouped fused attention (flash-style: no (Tq,Tk) score matrix in HBM).
  * Replaces q*scale, QK^T, softmax, P.V of F.multi_head_attention_forward as called at
  * models/fusion_layers.py:161-163,204 (six cross blocks + three self blocks of MulT in ONE

@@ -29,7 +29,7 @@ SYMBOLS = (
     "mmf_sqnorm_f32", "mmf_adamw_step", "mmf_adamw_advance", "mmf_skinny_linear_fwd", "mmf_skinny_linear_dgrad", "mmf_skinny_linear_fwd_ex", "mmf_skinny_linear_dgrad_ex",
     "mmf_gat3_dense_fwd", "mmf_gat3_dense_bwd", "mmf_infonce_fwd", "mmf_infonce_bwd", "mmf_adaptive_combine_fwd",
     "mmf_adaptive_combine_bwd", "mmf_adaptive_attn_weights", "mmf_linear_narrow_fwd", "mmf_linear_narrow_bwd", "mmf_stack3_embed_fwd",
-    "mmf_stack3_embed_bwd", "mmf_rowmask_apply", "mmf_zero_ranges_f32",
+    "mmf_stack3_embed_bwd", "mmf_rowmask_apply", "mmf_zero_ranges_f32", "mmf_fusion_loss", "mmf_modality_dropout",
     "mmf_attn_weights_mean", "mmf_gemm_f32_grouped", "mmf_gemm_f32_batched", "mmf_softmax_rows_f32", "mmf_softmax_bwd_rows_f32",
     "mmf_layernorm_f32_fwd", "mmf_layernorm_f32_bwd", "mmf_bilstm_workspace_bytes", "mmf_bilstm_layer_fwd", "mmf_bilstm_layer_bwd", "mmf_swap01",
 )
@@ -156,6 +156,8 @@ def load() -> C.CDLL:
     lib.mmf_relu_bwd_mixed.argtypes = [vp, C.c_int, vp, C.c_int, vp, i64, vp]
     lib.mmf_skinny_linear_fwd.argtypes = [C.POINTER(SkinnyProblem), i32, i32, i32, vp]
     lib.mmf_skinny_linear_dgrad.argtypes = [C.POINTER(SkinnyProblem), i32, i32, f32, i32, vp]
+    lib.mmf_fusion_loss.argtypes = [vp, i32, vp, i32, i32, f32, C.POINTER(vp), C.POINTER(f32), i32, vp, vp, vp]
+    lib.mmf_modality_dropout.argtypes = [C.POINTER(vp), C.POINTER(vp), vp, i32, i32, f32, vp, C.c_uint32, i32, vp]
     lib.mmf_skinny_linear_fwd_ex.argtypes = [C.POINTER(SkinnyProblemEx), i32, i32, i32, C.POINTER(SkinnyExtra), vp]
     lib.mmf_skinny_linear_dgrad_ex.argtypes = [C.POINTER(SkinnyProblemEx), i32, i32, f32, i32, C.POINTER(SkinnyExtra), vp]
     lib.mmf_sqnorm_f32.argtypes = [vp, i64, vp, vp]

@@ -337,3 +337,99 @@ class _RowMask(torch.autograd.Function):
 def rowmask(x: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
     """y[b, :] = x[b, :] * mask[b]  (fp32 (B, d), fp32 (B,))."""
     return _RowMask.apply(x.float(), mask)
+
+
+# --------------------------------------------------------------------------------------------
+# ModalityDropout and the training-step loss as one launch each (round 4; csrc/loss.hip)
+# --------------------------------------------------------------------------------------------
+import ctypes as _C
+
+
+def _ptr3(ts):
+    return (_C.c_void_p * 3)(*[t.data_ptr() for t in ts])
+
+
+class _ModalityDropout(torch.autograd.Function):
+    """reference models/encoders.py:289-321 on the three (B, d) f32 feature tensors: masks drawn and applied by ONE kernel
+    (mmf_modality_dropout); the backward applies the saved (B, 3) masks with the same kernel."""
+
+    @staticmethod
+    def forward(ctx, t, a, v, p, site):
+        xs = [x.float().contiguous() for x in (t, a, v)]
+        B, d = xs[0].shape
+        ys = [torch.empty_like(x) for x in xs]
+        keep = torch.empty((B, 3), dtype=F32, device=xs[0].device)
+        lib.check(lib.load().mmf_modality_dropout(_ptr3(xs), _ptr3(ys), keep.data_ptr(), B, d, float(p), ops.rng_state().data_ptr(),
+                                                  int(site), 1, lib.stream_ptr()))
+        ctx.save_for_backward(keep)
+        ctx.mark_non_differentiable(keep)
+        return ys[0], ys[1], ys[2], keep
+
+    @staticmethod
+    def backward(ctx, gt, ga, gv, _gk):
+        keep, = ctx.saved_tensors
+        B = keep.shape[0]
+        ref = next(g for g in (gt, ga, gv) if g is not None)
+        gs = [(g if g is not None else torch.zeros_like(ref)).float().contiguous() for g in (gt, ga, gv)]
+        d = gs[0].shape[1]
+        dx = [torch.empty_like(g) for g in gs]
+        lib.check(lib.load().mmf_modality_dropout(_ptr3(gs), _ptr3(dx), keep.data_ptr(), B, d, 0.0, None, 0, 0, lib.stream_ptr()))
+        return dx[0], dx[1], dx[2], None, None
+
+
+def modality_dropout(t: torch.Tensor, a: torch.Tensor, v: torch.Tensor, p: float):
+    """-> (t', a', v', keep (B, 3)); masks from the build's counter-based RNG (mmfusion.ops: dropout section)"""
+    return _ModalityDropout.apply(t, a, v, float(p), ops.next_site())
+
+
+_ONE: dict = {}
+
+
+def loss_seed(device) -> torch.Tensor:
+    """the resident d(loss)/d(loss) = 1 tensor of ``backward_from``: a backward started with it costs the fused loss no launch"""
+    key = str(device)
+    if key not in _ONE:
+        _ONE[key] = torch.ones((), dtype=F32, device=device)
+    return _ONE[key]
+
+
+def backward_from(loss: torch.Tensor) -> None:
+    """loss.backward() without the fill kernel that builds the unit gradient (and, for ``fusion_loss``, without the
+    multiplications by it)"""
+    torch.autograd.backward([loss], [loss_seed(loss.device)])
+
+
+class _FusionLoss(torch.autograd.Function):
+    """mean CE(label_smoothing) over (B, C) logits + sum_j w_j * extra_j (device scalars): value and d/d(logits) in one launch."""
+
+    @staticmethod
+    def forward(ctx, logits, targets, smoothing, weights, *extras):
+        logits = logits.float()
+        if logits.stride(1) != 1:
+            logits = logits.contiguous()
+        B, Cn = logits.shape
+        ex = [e.float().reshape(1) for e in extras]
+        loss = torch.empty((), dtype=F32, device=logits.device)
+        dlog = torch.empty((B, Cn), dtype=F32, device=logits.device)
+        n = len(ex)
+        pe = (_C.c_void_p * max(n, 1))(*[e.data_ptr() for e in ex])
+        pw = (_C.c_float * max(n, 1))(*[float(w) for w in weights])
+        lib.check(lib.load().mmf_fusion_loss(logits.data_ptr(), logits.stride(0), targets.data_ptr(), B, Cn, float(smoothing),
+                                             pe, pw, n, loss.data_ptr(), dlog.data_ptr(), lib.stream_ptr()))
+        ctx.save_for_backward(dlog)
+        ctx.weights = [float(w) for w in weights]
+        ctx.wt = [torch.full((), float(w), dtype=F32, device=logits.device) for w in weights] if n else []
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        dlog, = ctx.saved_tensors
+        if g.data_ptr() == loss_seed(g.device).data_ptr():       # started by backward_from: the gradient IS one
+            return (dlog, None, None, None, *ctx.wt)
+        return (dlog * g, None, None, None, *[g * w for w in ctx.weights])
+
+
+def fusion_loss(logits: torch.Tensor, targets: torch.Tensor, smoothing: float, extras, weights) -> torch.Tensor:
+    if targets.dtype != torch.int64:
+        targets = targets.long()
+    return _FusionLoss.apply(logits, targets.contiguous(), float(smoothing), list(weights), *extras)

@@ -344,13 +344,32 @@ def load_checkpoint(path: str, module: torch.nn.Module, optimizer: Optional["Fus
 def fusion_loss(outputs: Dict, targets: torch.Tensor, label_smoothing: float = 0.1) -> torch.Tensor:
     """reference advanced_trainer.py:139-166 (aux terms only when the batch carries them — the
     reference's ``hasattr(batch, 'valence')`` on a dict is always False)."""
-    loss = F.cross_entropy(outputs["emotion_logits"], targets, label_smoothing=label_smoothing)
+    logits = outputs["emotion_logits"]
     cl = outputs.get("contrastive_losses") or {}
+    if logits.is_cuda and logits.dim() == 2 and logits.shape[1] <= 64 and targets.dim() == 1:
+        # one launch for the value and the gradient with respect to the logits (csrc/loss.hip); the torch formulation below is
+        # ~35 elementwise launches of a few hundred bytes each, forward and backward
+        from . import small_ops
+        extras, weights = list(cl.values()), [0.1] * len(cl)
+        if "distillation_loss" in outputs:
+            extras.append(outputs["distillation_loss"])
+            weights.append(0.5)
+        return small_ops.fusion_loss(logits, targets, label_smoothing, extras, weights)
+    loss = F.cross_entropy(logits, targets, label_smoothing=label_smoothing)
     if cl:
         loss = loss + 0.1 * sum(cl.values())
     if "distillation_loss" in outputs:
         loss = loss + 0.5 * outputs["distillation_loss"]
     return loss
+
+
+def backward_from(loss: torch.Tensor) -> None:
+    """``loss.backward()`` for a loss of ``fusion_loss``: seeds autograd with a resident unit gradient (no fill launch)."""
+    if loss.is_cuda:
+        from . import small_ops
+        small_ops.backward_from(loss)
+    else:
+        loss.backward()
 
 
 class FusionTrainStep:
@@ -387,7 +406,7 @@ class FusionTrainStep:
         outputs = dict(out) if isinstance(out, dict) else {}
         outputs["emotion_logits"] = self.head(fused)
         loss = fusion_loss(outputs, targets)
-        loss.backward()
+        backward_from(loss)
         self.arena.finalize_grads()
         return loss
 

@@ -197,7 +197,8 @@ class VideoEncoder(_FusionBase):
 
 class ModalityDropout(nn.Module):
     """Per-sample Bernoulli keep-masks, p = dropout_rate, **no** 1/(1-p) rescale, at least one
-    modality kept (reference :289-321).  The masks are (B, 1) — sampling stays on torch's RNG."""
+    modality kept (reference :289-321).  On the GPU (2-D features) the masks come from the build's counter-based RNG and are
+    drawn and applied by one kernel; the torch formulation serves CPU tensors, 3-D features and the fp32 parity mode."""
 
     def __init__(self, dropout_rate: float = 0.1):
         super().__init__()
@@ -207,14 +208,18 @@ class ModalityDropout(nn.Module):
         if not training:
             return text_features, audio_features, video_features
         B, dev = text_features.size(0), text_features.device
+        if (text_features.is_cuda and text_features.dim() == 2 and text_features.shape[1] % 4 == 0
+                and text_features.shape == audio_features.shape == video_features.shape and not ops.fp32_mode()):
+            # masks drawn and applied by ONE kernel from the build's counter-based RNG (csrc/loss.hip modality_dropout_kernel:
+            # Bernoulli(1 - p) per (sample, modality), a sample with nothing left gets one modality back) — the torch formulation
+            # below is ~16 launches forward and 6 backward for 3 x B numbers
+            from mmfusion import small_ops as sops
+            t, a, v, _ = sops.modality_dropout(text_features, audio_features, video_features, self.dropout_rate)
+            return t, a, v
         keep = torch.rand(B, 3, device=dev) > self.dropout_rate
         # samples that lost all three modalities get one back at random (:308-314) — written without the
         # reference's data-dependent branch so that nothing synchronises with the host (hipGraph-capturable)
         choice = torch.nn.functional.one_hot(torch.randint(0, 3, (B,), device=dev), 3).bool()
         keep = torch.where(keep.any(dim=1, keepdim=True), keep, choice)
         k = keep.float()
-        if text_features.is_cuda and text_features.dim() == 2:
-            from mmfusion import small_ops as sops               # y[b, :] = x[b, :] * keep[b, m]: HIP kernel
-            return (sops.rowmask(text_features, k[:, 0].contiguous()), sops.rowmask(audio_features, k[:, 1].contiguous()),
-                    sops.rowmask(video_features, k[:, 2].contiguous()))
         return text_features * k[:, 0:1], audio_features * k[:, 1:2], video_features * k[:, 2:3]

@@ -88,6 +88,53 @@ def test_ffn_dropout_matches_reference_given_the_mask():
     assert rel(mod[0].bias.grad, b1.grad) < 3e-2 and rel(mod[1].bias.grad, b2.grad) < 3e-2
 
 
+@pytest.mark.parametrize("relu", [True, False])
+@pytest.mark.parametrize("f32_in", [True, False])
+@pytest.mark.parametrize("p", [0.0, 0.3])
+def test_row_linear_folds_cast_dropout_and_relu_gradient(relu, f32_in, p):
+    """mmfusion.ops._RowLinear (round 4; mmf_skinny_linear_*_ex): a group of two (B, d)-row linears with an f32 or bf16 input,
+    ReLU or not, dropout or not, both output dtypes from one launch.  Forward against fp32 arithmetic on the bf16-rounded
+    operands with the mask read off the output (a dropped element is exactly 0); backward against fp32 autograd WITH that mask:
+    the dgrad kernel regenerates it (dropout without ReLU) or gates by the saved output (ReLU), and leaves the gated gradient
+    behind for the deferred weight-gradient launch."""
+    from mmfusion import arena as arena_mod
+    from mmfusion.ops import LinearSpec, W
+    M, K, N1, N2 = 16, 1536, 520, 264
+    torch.manual_seed(0)
+    mod = torch.nn.ModuleList([torch.nn.Linear(K, N1), torch.nn.Linear(K, N2)]).cuda()
+    arena = arena_mod.ensure(mod)
+    arena.zero_grad()
+    xs = [rnd(M, K, seed=10 + i).to(DEV) for i in range(2)]
+    xin = [(x if f32_in else x.bfloat16()).clone().requires_grad_(True) for x in xs]
+    ops.seed_dropout(11)
+    ops.begin_training_forward()
+    outs = ops.linear_group([(x, LinearSpec(W(m.weight), W(m.bias), relu), None) for x, m in zip(xin, mod)], out_f32=True,
+                            dropout_p=p, dual=True)
+    gys = [rnd(M, n, seed=20 + i).to(DEV) for i, n in enumerate((N1, N2))]
+    # gradient into the f32 copy of problem 0 and into the bf16 copy of problem 1 (as the next linear would send it)
+    torch.autograd.backward([outs[0][0], outs[1][1]], [gys[0], gys[1].bfloat16()])
+    torch.cuda.synchronize()
+    for i, (m, x, (y, y16), gy) in enumerate(zip(mod, xs, outs, gys)):
+        assert y.dtype == torch.float32 and y16.dtype == torch.bfloat16 and torch.equal(y16, y.bfloat16())
+        W16 = ops.shadow(m.weight).float().cpu().requires_grad_(True)
+        b = m.bias.detach().cpu().clone().requires_grad_(True)
+        xr = x.bfloat16().float().cpu().requires_grad_(True)
+        z = xr @ W16.t() + b
+        z = torch.relu(z) if relu else z
+        mask = (y.detach().cpu() != 0).float() if p > 0 else torch.ones_like(z)
+        if p > 0:
+            live = (z.detach() != 0)
+            kept = float(mask[live].mean())
+            assert abs(kept - (1 - p)) < 0.03, kept
+        yr = z * mask / (1 - p)
+        assert rel(y, yr) < 1e-5
+        g = gy.cpu() if i == 0 else gy.bfloat16().float().cpu()
+        yr.backward(g)
+        assert rel(xin[i].grad, xr.grad) < 2e-2, (i, rel(xin[i].grad, xr.grad))
+        assert xin[i].grad.dtype == (torch.float32 if f32_in else torch.bfloat16)
+        assert rel(m.weight.grad, W16.grad) < 2e-2 and rel(m.bias.grad, b.grad) < 2e-2
+
+
 @pytest.mark.parametrize("B,H,dh,Tq,Tk", [(2, 2, 96, 70, 40), (1, 2, 64, 33, 150), (2, 1, 96, 130, 96)])
 def test_attention_dropout_matches_reference_given_the_mask(B, H, dh, Tq, Tk):
     """P_dropped is read out by making V a shifted identity; fwd and bwd are then checked with that mask"""
