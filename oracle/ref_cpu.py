@@ -403,7 +403,7 @@ def hierarchical_fusion(P: Params, pre: str, text: Tensor, audio: Tensor, video:
     branches consume the (B,d) tensors.  With ``mult_inputs=None`` this is the literal
     reference semantics (*hier-ref*).  ``unit_masks`` (parity instrument, tests/test_configs_gpu.py): 0/1 masks by
     output key applied to the four ReLU-terminated branch outputs before they are returned and concatenated, the same
-    masks the HIP module takes through ``HierarchicalFusion.unit_masks`` — units whose ReLU state differs between the
+    masks the tests apply to the HIP module (tests/helpers.py ``masked_hierarchical_fusion``) — units whose ReLU state differs between the
     two sides are switched off on both, so the gradients can be compared tightly.  Key ``meta_hidden`` masks the meta
     MLP's hidden layer the same way; ``capture`` (a dict) receives that hidden layer."""
     early = early_fusion(P, pre + "early_fusion.", text, audio, video)

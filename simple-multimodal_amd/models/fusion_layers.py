@@ -578,9 +578,8 @@ class HierarchicalFusion(_FusionBase):
         self.meta_fusion = nn.Sequential(nn.Linear(5 * d, 2 * d), nn.ReLU(), nn.Dropout(config.fusion_dropout),
                                          nn.Linear(2 * d, d))
 
-    def forward(self, text_features, audio_features, video_features,
-                compute_contrastive_loss: bool = False) -> Dict[str, torch.Tensor]:
-        p = _p(self, self.config.fusion_dropout)
+    def _branches(self, text_features, audio_features, video_features, compute_contrastive_loss: bool):
+        """-> (early, mult, graph, con, ada): the five branch results (:486-500)"""
         seq = (text_features, audio_features, video_features)
         if text_features.dim() == 3:
             d = text_features.shape[-1]
@@ -608,26 +607,21 @@ class HierarchicalFusion(_FusionBase):
             graph = self.graph_fusion(text_features, audio_features, video_features)
             con = self.contrastive_fusion(text_features, audio_features, video_features, compute_contrastive_loss)
             ada = self.adaptive_fusion(text_features, audio_features, video_features)
-        um = getattr(self, "unit_masks", None)
-        if um:
-            # parity instrument (tests/test_configs_gpu.py, oracle.ref_cpu.hierarchical_fusion(unit_masks=...)): 0/1 masks
-            # on the four ReLU-terminated branch outputs, so that the few top-level units whose ReLU state differs from
-            # the bf16-storage oracle's (pre-activations within a rounding error of zero) are off on BOTH sides
-            mult, con, ada = dict(mult), dict(con), dict(ada)
-            early = early * um["early_features"] if "early_features" in um else early
-            for dct, key in ((mult, "mult_features"), (con, "contrastive_features"), (ada, "adaptive_features")):
-                if key in um:
-                    dct["fused_features"] = dct["fused_features"] * um[key]
+        return early, mult, graph, con, ada
+
+    def _meta_hidden(self, allf: torch.Tensor, p: float) -> torch.Tensor:
+        """the meta MLP's hidden layer (:507-508): Linear(5d, 2d) + ReLU + Dropout on the concatenated branch outputs"""
+        return ops.linear(allf, *_wb(self.meta_fusion[0]), relu=True, dropout_p=p)
+
+    def forward(self, text_features, audio_features, video_features,
+                compute_contrastive_loss: bool = False) -> Dict[str, torch.Tensor]:
+        p = _p(self, self.config.fusion_dropout)
+        early, mult, graph, con, ada = self._branches(text_features, audio_features, video_features, compute_contrastive_loss)
         allf = torch.cat([early, mult["fused_features"], graph, con["fused_features"],
                           ada["fused_features"]], dim=-1)                             # :503-506, f32 (B, 5d): narrowed by the linear itself
         if ops.fp32_mode():
             allf = _as_rows(allf)
-        h = ops.linear(allf, *_wb(self.meta_fusion[0]), relu=True, dropout_p=p)
-        if um:
-            if "capture" in um:
-                um["capture"]["meta_hidden"] = h.detach()
-            if "meta_hidden" in um:
-                h = h * um["meta_hidden"].to(h.dtype)
+        h = self._meta_hidden(allf, p)
         final = ops.linear(h, *_wb(self.meta_fusion[3]), out_f32=True)
         return {"fused_features": final, "early_features": early, "mult_features": mult["fused_features"],
                 "graph_features": graph, "contrastive_features": con["fused_features"],

@@ -94,3 +94,38 @@ def l2_rel(a, b):
     """||a-b||_2 / ||b||_2"""
     a, b = a.detach().float().cpu(), b.detach().float().cpu()
     return float((a - b).norm() / max(float(b.norm()), 1e-12))
+
+
+def masked_hierarchical_fusion(config):
+    """HierarchicalFusion with the flip-aware parity instrument of tests/test_configs_gpu.py — a TEST-side subclass (round 4:
+    the product module carries no such hook any more): ``unit_masks`` (dict of 0/1 tensors by output key) switches top-level
+    ReLU units off on the four ReLU-terminated branch outputs and on the meta MLP's hidden layer, exactly as
+    ``oracle.ref_cpu.hierarchical_fusion(unit_masks=...)`` does on the oracle side; ``unit_masks["capture"]`` (a dict)
+    receives the hidden layer."""
+    from models import fusion_layers as fl
+
+    class MaskedHierarchicalFusion(fl.HierarchicalFusion):
+        unit_masks = None
+
+        def _branches(self, *args, **kwargs):
+            early, mult, graph, con, ada = super()._branches(*args, **kwargs)
+            um = self.unit_masks
+            if um:
+                mult, con, ada = dict(mult), dict(con), dict(ada)
+                early = early * um["early_features"] if "early_features" in um else early
+                for dct, key in ((mult, "mult_features"), (con, "contrastive_features"), (ada, "adaptive_features")):
+                    if key in um:
+                        dct["fused_features"] = dct["fused_features"] * um[key]
+            return early, mult, graph, con, ada
+
+        def _meta_hidden(self, allf, p):
+            h = super()._meta_hidden(allf, p)
+            um = self.unit_masks
+            if um:
+                if "capture" in um:
+                    um["capture"]["meta_hidden"] = h.detach()
+                if "meta_hidden" in um:
+                    h = h * um["meta_hidden"].to(h.dtype)
+            return h
+
+    return MaskedHierarchicalFusion(config)

@@ -54,10 +54,10 @@ def test_hier_seq_matches_oracle(name, B, Ts, d, H):
     """BASELINE configs[2]: all nine output keys (incl. the three contrastive losses and the returned (B,3,3)
     attention weights), input gradients (which sum the MulT path and the pooled path) and one parameter gradient per
     branch."""
-    from models import fusion_layers as fl
+    from helpers import masked_hierarchical_fusion
     cfg = _hier_cfg(d, H, d, 3)
     torch.manual_seed(synth.WEIGHT_SEED)
-    m = fl.HierarchicalFusion(cfg)
+    m = masked_hierarchical_fusion(cfg)          # the product module + the test-side unit-mask instrument (tests/helpers.py)
     P = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
     xs = synth.make_features(B, Ts, d)
     xr = [x.clone().requires_grad_(True) for x in xs]
@@ -105,7 +105,7 @@ def test_hier_seq_matches_oracle(name, B, Ts, d, H):
     # roundings averaged over T = 512), so a handful of top-level units whose pre-activation is within that of zero are on
     # in one and off in the other, and ONE such unit moves every upstream gradient by ~1.3e-2.  Round 2 halved the fp32
     # bound for this; now the flips are COUNTED (they must be few) and those units are switched off on both sides
-    # (HierarchicalFusion.unit_masks / hierarchical_fusion(unit_masks=...): the four ReLU-terminated branch outputs and the
+    # (tests/helpers.py masked_hierarchical_fusion / hierarchical_fusion(unit_masks=...): the four ReLU-terminated branch outputs and the
     # meta MLP's hidden layer), after which the gradients must agree to the same 2e-2 as at the small size.
     from test_parity_gpu import GIN_L2_BF16, GP_L2_BF16, OUT_BF16
     for k in HIER_KEYS:
