@@ -399,6 +399,17 @@ def backward_from(loss: torch.Tensor) -> None:
     torch.autograd.backward([loss], [loss_seed(loss.device)])
 
 
+_SCALARS: dict = {}
+
+
+def _resident_scalar(v: float, device) -> torch.Tensor:
+    """a 0-d f32 tensor holding v, created once per (value, device): gradients of constant weight cost no fill launch"""
+    key = (v, str(device))
+    if key not in _SCALARS:
+        _SCALARS[key] = torch.full((), v, dtype=F32, device=device)
+    return _SCALARS[key]
+
+
 class _FusionLoss(torch.autograd.Function):
     """mean CE(label_smoothing) over (B, C) logits + sum_j w_j * extra_j (device scalars): value and d/d(logits) in one launch."""
 
@@ -418,7 +429,7 @@ class _FusionLoss(torch.autograd.Function):
                                              pe, pw, n, loss.data_ptr(), dlog.data_ptr(), lib.stream_ptr()))
         ctx.save_for_backward(dlog)
         ctx.weights = [float(w) for w in weights]
-        ctx.wt = [torch.full((), float(w), dtype=F32, device=logits.device) for w in weights] if n else []
+        ctx.wt = [_resident_scalar(float(w), logits.device) for w in weights]
         return loss
 
     @staticmethod
