@@ -260,6 +260,17 @@ class ParamArena:
         base = self.master.data_ptr()
         return all(p.data_ptr() == base + 4 * o for p, o in zip(self.params, self.offsets))
 
+    masters_stale = None               # set by FusedAdamW.launch_sharded (ZeRO-1) to the optimiser, cleared by its gather_masters()
+
+    def require_fresh_masters(self, what: str) -> None:
+        """A sharded optimiser step leaves this rank's fp32 masters outside its shard one step behind (the bf16 shadow every rank
+        computes with IS current).  Anything that reads the masters calls this first: it raises — gathering is a collective
+        that cannot be started from one rank's read — and names the fix (silently recasting the shadow from stale
+        masters would revert weights on this rank)."""
+        if self.masters_stale is not None:
+            raise RuntimeError(f"{what}: the fp32 masters of this rank are stale outside its optimiser shard (ZeRO-1 step); call "
+                               "FusedAdamW.gather_masters() on every rank first (save_checkpoint does)")
+
     def mark_shadow_fresh(self) -> None:
         """Called by ``mmfusion.train.FusedAdamW`` after its kernel has written masters AND shadow:
         the next forward needs no cast (until some other writer touches a parameter)."""
@@ -273,6 +284,7 @@ class ParamArena:
             return                     # the fused optimiser keeps the shadow in step with the masters
         self._shadow_fresh = False
         if force or v != self._cast_version:
+            self.require_fresh_masters("recasting the bf16 shadow from the fp32 masters")
             L, e = lib.load(), self.early_numel
             if OVERLAP and 0 < e < self.numel:
                 # late block (everything but the in-projections) on the side stream, in parallel with the
@@ -305,6 +317,17 @@ def ensure(module: torch.nn.Module, refresh: Optional[bool] = None) -> ParamAren
     if not ok or arena is None:
         arena = ParamArena(module)
         module._mmf_arena_root = arena
+        if not getattr(module, "_mmf_state_dict_guard", False):
+            # module.state_dict() reads the fp32 masters: refuse while a ZeRO-1 step has left them stale on this rank
+            def _guard(mod, prefix, keep_vars):
+                ar = getattr(mod, "_mmf_arena_root", None)
+                if ar is not None:
+                    ar.require_fresh_masters("module.state_dict()")
+            try:
+                module.register_state_dict_pre_hook(_guard)
+                module._mmf_state_dict_guard = True
+            except AttributeError:                                 # (torch < 2.0)
+                pass
     arena.attach_grads()
     arena.refresh(force=bool(refresh))
     return arena

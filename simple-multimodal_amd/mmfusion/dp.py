@@ -165,17 +165,35 @@ class BackwardExchange:
     the mean all-reduce of the gradient-arena runs they complete is started right behind them, while the main stream
     goes on with the backward pass; ``finish()`` (after ``arena.finalize_grads()``) starts the exchange of everything no
     round covered — biases, LayerNorm vectors, torch-produced gradients, regions that got no gradient — and waits for
-    all of it, so the arena holds the mean over ranks of every element, each reduced exactly once.
+    all of it, so the arena holds the mean over ranks of every element.
+
+    **Every rank issues the same collectives in the same order** (round 4).  What goes on the wire early is a PLAN —
+    per round, the element runs of the arena — that all ranks hold identically: a step records the runs its own rounds
+    completed, ``finish()`` compares a hash of that record across ranks (one three-number MAX all-reduce) and only an
+    agreed record becomes the next step's plan.  While a plan is active a round is sent early only if it completes exactly the
+    planned runs in the planned position; the first deviation (a branch switched off by modality dropout on this rank only, a
+    weight used a different number of times, more or fewer problems than last step) stops this rank's early sends, and
+    ``finish()`` sends the remaining planned rounds — in plan order — before the gaps, so the sequence of collectives is the
+    plan's on every rank whatever its own backward did.  A gradient region written AGAIN after its round went out (a late
+    writer the plan did not know) first waits for that round's collective, accumulates onto the mean, and is marked dirty;
+    dirty flags are part of the three-number all-reduce and any rank's flag makes every rank re-send the planned runs: the mean
+    of (mean + late contribution) is the correct mean, because the mean of values that are already identical is the value.
 
     Eager steps only: nothing here is captured into a hipGraph (the collectives run on RCCL's own stream).  Unmeasured
-    on RCCL hardware; the logic is covered by tests/test_dp_rounds_cpu.py on two gloo ranks."""
+    on RCCL hardware; the logic is covered by tests/test_dp_rounds_cpu.py on two gloo ranks, including a
+    step whose graph differs between the ranks."""
 
     def __init__(self, arena, rounds: int = 4, compress: Optional[str] = "bf16", group=None,
                  bucket_bytes: int = DEFAULT_BUCKET_BYTES):
         self.arena, self.rounds, self.compress, self.group, self.bucket_bytes = arena, rounds, compress, group, bucket_bytes
-        self._handles: List[_RangePending] = []
-        self._sent: List[tuple] = []                     # (start, end) element runs already on the wire this step
+        self._handles: List[tuple] = []                  # (runs, [_RangePending]) per early-sent round, in order
+        self._plan: Optional[List[List[tuple]]] = None   # agreed by all ranks at the end of the previous step
+        self._observed: List[List[tuple]] = []           # this step's rounds, as run lists
+        self._sent_rounds = 0                            # planned rounds this rank has put on the wire so far
+        self._deviated = False
+        self._dirty = False
         self.rounds_seen = 0                             # hook calls of the current step (tests, logging)
+        self.resends = 0                                 # steps in which the planned runs were exchanged a second time (tests)
 
     def install(self) -> "BackwardExchange":
         from . import ops
@@ -201,10 +219,16 @@ class BackwardExchange:
         import contextlib
         return contextlib.nullcontext()
 
+    def _span(self, t: torch.Tensor) -> tuple:
+        """(first, one past the last) arena element a gradient view may be written at: for a row-strided view (a column block of
+        a packed weight) the last row ends at (rows - 1) * ld + cols, not at numel (as ops._wgrad_rounds)"""
+        first = (t.data_ptr() - self.arena.grads.data_ptr()) // 4
+        n = (t.shape[0] - 1) * t.stride(0) + t.shape[1] if t.dim() == 2 else t.numel()
+        return first, first + n
+
     def _runs(self, problems) -> List[tuple]:
         """coalesced (start, end) element runs of the weight-gradient regions of `problems` inside the arena"""
-        base = self.arena.grads.data_ptr()
-        spans = sorted(((q[2].data_ptr() - base) // 4, (q[2].data_ptr() - base) // 4 + q[2].numel()) for q in problems)
+        spans = sorted(self._span(q[2]) for q in problems)
         runs: List[list] = []
         for s0, e0 in spans:
             s0, e0 = s0 // 64 * 64, (e0 + 63) // 64 * 64            # parameters start on 64-element boundaries
@@ -214,16 +238,50 @@ class BackwardExchange:
                 runs.append([s0, e0])
         return [(a, min(b, self.arena.numel)) for a, b in runs]
 
+    def _send(self, runs) -> None:
+        with self._stream():
+            hs = [allreduce_grads_range_async(self.arena, s0, e0, self.group, self.bucket_bytes, self.compress) for s0, e0 in runs]
+        self._handles.append((runs, hs))
+
+    def _late_writers(self, problems) -> None:
+        """a problem about to write a region whose round is already on the wire: wait for that collective first (the GEMM
+        must not run under it), then the accumulate lands on the mean and the region is exchanged again in finish()"""
+        for q in problems:
+            s0, e0 = self._span(q[2])
+            for runs, hs in self._handles:
+                if any(a < e0 and s0 < b for a, b in runs):
+                    for h in hs:
+                        h.finish()
+                    self._dirty = True
+
     def _on_round(self, problems, final: bool) -> None:
         self.rounds_seen += 1
         if problems:
+            self._late_writers(problems)
             self._issue(problems)
-        if final or not problems:
+        if final:
             return                                       # the last round's regions go out with the rest in finish()
-        with self._stream():
-            for s0, e0 in self._runs(problems):
-                self._handles.append(allreduce_grads_range_async(self.arena, s0, e0, self.group, self.bucket_bytes, self.compress))
-                self._sent.append((s0, e0))
+        runs = self._runs(problems) if problems else []
+        i = len(self._observed)
+        self._observed.append(runs)
+        if self._plan is None or self._deviated:
+            return
+        if i < len(self._plan) and runs == self._plan[i] and self._sent_rounds == i:
+            self._send(runs)
+            self._sent_rounds = i + 1
+        else:
+            self._deviated = True                        # this rank's backward left the plan: no more early sends this step
+
+    def _agree(self, digest: int) -> tuple:
+        """-> (any rank dirty, all ranks hold the same digest): ONE MAX all-reduce of [dirty, digest, -digest]"""
+        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        if world == 1:
+            return self._dirty, True
+        dev = self.arena.grads.device
+        t = torch.tensor([int(self._dirty), digest, -digest], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        v = t.tolist()
+        return bool(v[0]), v[1] == -v[2] and v[1] == digest
 
     def finish(self) -> None:
         """Call after backward AND ``arena.finalize_grads()``: exchange what no round sent, then wait for everything."""
@@ -231,18 +289,40 @@ class BackwardExchange:
             from . import ops
             if ops._wgrad_stream is not None:            # the final round's GEMMs ran on the wgrad stream
                 torch.cuda.current_stream().wait_stream(ops._wgrad_stream)
-        pos = 0
-        for s0, e0 in sorted(self._sent) + [(self.arena.numel, self.arena.numel)]:
+        plan = self._plan or []
+        for i in range(self._sent_rounds, len(plan)):    # planned rounds this rank did not reach: same collectives, only later
+            self._send(plan[i])
+        covered = sorted(r for runs in plan for r in runs)
+        pos, rest = 0, []
+        for s0, e0 in covered + [(self.arena.numel, self.arena.numel)]:
             if s0 > pos:
-                self._handles.append(allreduce_grads_range_async(self.arena, pos, s0, self.group, self.bucket_bytes, self.compress))
+                rest.append((pos, s0))
             pos = max(pos, e0)
-        for h in self._handles:
+        tail = [allreduce_grads_range_async(self.arena, a, b, self.group, self.bucket_bytes, self.compress) for a, b in rest]
+        for _, hs in self._handles:
+            for h in hs:
+                h.finish()
+        for h in tail:
             h.finish()
-        self._handles, self._sent, self.rounds_seen = [], [], 0
+        # one small all-reduce: does any rank hold a region written after its round went out, and do all ranks agree on what
+        # this step's rounds completed (the candidate plan of the next step)?
+        import hashlib
+        rec = self._observed if not self._deviated or self._plan is None else None
+        digest = int.from_bytes(hashlib.sha256(repr(rec).encode()).digest()[:7], "big") if rec is not None else 0
+        dirty, same = self._agree(digest)
+        if dirty:
+            self.resends += 1
+            again = [allreduce_grads_range_async(self.arena, a, b, self.group, self.bucket_bytes, self.compress) for a, b in covered]
+            for h in again:
+                h.finish()
+        self._plan = ([r for r in rec if r] or None) if (same and rec is not None and digest != 0) else None
+        self._handles, self._observed, self._sent_rounds, self._deviated, self._dirty, self.rounds_seen = [], [], 0, False, False, 0
 
 
 def broadcast_params(arena, src: int = 0, group=None) -> None:
     """Make the replicas identical (rank ``src``'s masters win), then refresh the bf16 shadow."""
+    if hasattr(arena, "require_fresh_masters"):
+        arena.require_fresh_masters("broadcasting the fp32 masters")
     if dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.broadcast(arena.master, src=src, group=group)
     arena.refresh(force=True)

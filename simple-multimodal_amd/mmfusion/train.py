@@ -84,12 +84,19 @@ class FusedAdamW:
         self.rank = torch.distributed.get_rank(group) if self.world > 1 else 0
         self.sharded = bool(shard) and self.world > 1
         if self.sharded:
+            from . import ops as _ops
+            if _ops.fp32_mode():
+                raise RuntimeError("FusedAdamW(shard=True): the fp32 parity mode reads the fp32 MASTERS as weights, and the sharded "
+                                   "step keeps only this rank's shard of them up to date — use the replicated optimiser there")
             if arena.capacity % (64 * self.world):
                 raise ValueError(f"arena capacity {arena.capacity} does not divide into {self.world} 64-aligned shards")
             self.shard_len = arena.capacity // self.world
             self.shard_start = self.rank * self.shard_len
         else:
             self.shard_len, self.shard_start = arena.numel, 0
+        self._tail = (torch.zeros(max(0, arena.numel - arena.small_start), dtype=torch.float32, device=dev)
+                      if self.sharded else None)         # the small-parameter exchange buffer of launch_sharded, allocated once
+        self._grad_scale_base = 1.0                      # the caller's grad_scale (set_hparams): the sharded step multiplies 1/world in
         self.exp_avg = torch.zeros(self.shard_len, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(self.shard_len, dtype=torch.float32, device=dev)
         self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
@@ -159,6 +166,7 @@ class FusedAdamW:
         Adam beta1 when the schedule cycles it (``one_cycle``); the bias correction uses it, as torch's Adam does."""
         self.sync_step()                     # graph replays of advance() moved the device counter, not self.t
         self.t += 1
+        self._grad_scale_base = float(grad_scale)
         self._upload(self._static_hparams(self.lr if lr is None else lr, grad_scale, beta1))
         if self._cuda:
             self.step_dev.fill_(self.t)      # keep the device counter in step for a later advance()
@@ -199,8 +207,9 @@ class FusedAdamW:
         a, n, s = self.arena, self.shard_len, self.shard_start
         mine = a.grads_full[s:s + n]
         dist.reduce_scatter_tensor(mine, a.grads_full, op=dist.ReduceOp.SUM, group=self.group)
-        # the kernels scale every gradient by hparams[8] (grad_scale): the mean over ranks
-        self.hparams[8:9].fill_(1.0 / self.world)
+        # the kernels scale every gradient by hparams[8] (grad_scale): the caller's scale (loss scaling, gradient accumulation;
+        # set_hparams) times the mean over ranks — multiplied in from the saved base, not overwritten
+        self.hparams[8:9].fill_(self._grad_scale_base / self.world)
         if self.max_grad_norm:
             self.gnorm_sq.zero_()
             self._sqnorm_range(s, n)                         # of the SUMMED shard: the kernel applies the 1/N itself
@@ -212,13 +221,20 @@ class FusedAdamW:
         # rank — each rank contributes the part of the tail it owns, zeros elsewhere, one sum all-reduce of ~1 MB.
         t0, t1 = a.small_start, a.numel
         if t1 > t0:
-            tmp = torch.zeros(t1 - t0, dtype=torch.float32, device=a.master_full.device)
+            tmp = self._tail
+            tmp.zero_()
             lo, hi = max(t0, s), min(t1, s + n)
             if hi > lo:
                 tmp[lo - t0:hi - t0].copy_(a.master_full[lo:hi])
             dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=self.group)
             a.master_full[t0:t1].copy_(tmp)
+        # restore the caller's scale on the device (a later replicated launch, or a host that reads hparams back, sees it)
+        self.hparams[8:9].fill_(self._grad_scale_base)
         a.mark_shadow_fresh()
+        # from here on this rank's fp32 masters OUTSIDE its shard (and outside the small tail) are one step behind: every reader
+        # of the masters — arena.refresh() when it would really cast, dp.broadcast_params, module.state_dict() — gathers first
+        # (or raises where a collective cannot be assumed); gather_masters() clears the flag
+        a.masters_stale = self
 
     def gather_masters(self) -> None:
         """Sharded mode: bring every rank's fp32 masters up to date (all-gather, 4 B/param) — before a checkpoint, an
@@ -227,6 +243,7 @@ class FusedAdamW:
             import torch.distributed as dist
             a, n, s = self.arena, self.shard_len, self.shard_start
             dist.all_gather_into_tensor(a.master_full, a.master_full[s:s + n].clone(), group=self.group)
+            a.masters_stale = None
 
     def _full_moments(self):
         """(exp_avg, exp_avg_sq) over the whole arena: the shard's in replicated mode, gathered in sharded mode."""
@@ -313,8 +330,18 @@ def save_checkpoint(path: str, module: torch.nn.Module, optimizer: Optional["Fus
     """Write the reference's checkpoint layout (advanced_trainer.py:396-411): epoch, model_state_dict,
     optimizer_state_dict, scheduler_state_dict, metrics, config.  ``module.state_dict()`` has the reference's keys
     and shapes, so the reference's ``load_pretrained_model`` / ``load_state_dict`` read the file as their own."""
-    if optimizer is not None:
-        optimizer.gather_masters()           # sharded optimiser: the other ranks' shards of the fp32 masters (a collective)
+    if optimizer is not None and optimizer.sharded:
+        # Sharded optimiser: gathering the other ranks' shards of the masters and moments is a COLLECTIVE — every rank of the group
+        # must call save_checkpoint (and only rank 0 needs to pass a path it really writes to).  The usual rank-0-only save of
+        # the reference trainer would wait for ranks that never arrive; the barrier below turns that into an error after
+        # MMF_CKPT_BARRIER_S seconds (default 120) instead of a silent hang.
+        import datetime
+        import os as _os
+        import torch.distributed as dist
+        work = dist.barrier(group=optimizer.group, async_op=True)
+        if not work.wait(timeout=datetime.timedelta(seconds=float(_os.environ.get("MMF_CKPT_BARRIER_S", "120")))):
+            raise RuntimeError("save_checkpoint with a sharded optimiser is a collective: call it on EVERY rank of the group")
+        optimizer.gather_masters()
     ckpt = {"epoch": int(epoch),
             "model_state_dict": {k: v.detach().cpu().clone() for k, v in module.state_dict().items()},
             "optimizer_state_dict": optimizer.state_dict(module.parameters()) if optimizer is not None else {},

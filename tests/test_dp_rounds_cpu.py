@@ -15,7 +15,7 @@ import torch.multiprocessing as mp
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, scenario="plain"):
     for p in (REPO, os.path.join(REPO, "simple-multimodal_amd")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -53,9 +53,23 @@ def _worker(rank, world, port, q):
             ops.queue_wgrad(g, x, ar.w(ctx.i), None)     # dW = g^T x, deferred: exactly the product Functions' call
             return g @ Ws[ctx.i], None
 
-    order = [0, 1, 2, 3, 4, 5, 2]                        # layer 2 is applied twice: two writers of one gradient region
+    base_order = [0, 1, 2, 3, 4, 5, 2]                   # layer 2 is applied twice: two writers of one gradient region
+
+    def order_of(step):
+        """plain: the same chain every step.  diverge (round 4): step 3 — rank 1 alone drops layer 5 (as a branch
+        switched off by modality dropout on one rank would); step 6 — both ranks use layer 5 a second time, at the head of the
+        chain, unknown to the plan: its region is written again at the very end of backward, after its round went out."""
+        if scenario == "diverge":
+            if step == 3 and rank == 1:
+                return [0, 1, 2, 3, 4, 2]
+            if step == 6:
+                return [5] + base_order                  # its backward comes LAST: layer 5's round went out long before
+        return base_order
+
+    order = base_order
 
     def fwd_bwd(x):
+        nonlocal order
         h = x.clone().requires_grad_(True)
         y = h
         for i in order:
@@ -80,7 +94,8 @@ def _worker(rank, world, port, q):
     for compress in (None, "bf16"):
         bx = Bx(ar, rounds=3, compress=compress).install()
         per_step = []
-        for step in range(3):
+        for step in range(3 if scenario == "plain" else 8):
+            order = order_of(step)
             x = torch.randn(8, d, generator=torch.Generator().manual_seed(1000 * step + rank))
             ar.grads.zero_()
             ar.grads[-128:] = float(rank + 1)            # something in the tail that only finish() can exchange
@@ -99,13 +114,14 @@ def _worker(rank, world, port, q):
             y.pow(2).sum().backward()
             local = torch.zeros(ar.numel)
             for i in range(nlayer):
-                local[i * d * d:(i + 1) * d * d] = Wr[i].grad.reshape(-1)
+                if Wr[i].grad is not None:               # (a layer this rank did not use leaves zeros)
+                    local[i * d * d:(i + 1) * d * d] = Wr[i].grad.reshape(-1)
             local[-128:] = float(rank + 1)
             ref = type("A", (), {})()
             ref.grads = local
             dp.allreduce_grads(ref, compress=compress, bucket_bytes=1 << 20)
             per_step.append((list(bx.log), float((got - ref.grads).abs().max()), float(ref.grads.abs().max()),
-                             float(got[-128:].mean())))
+                             float(got[-128:].mean()), bx.resends))
         bx.remove()
         results[str(compress)] = per_step
     q.put((rank, results))
@@ -126,7 +142,7 @@ def test_exchange_inside_backward_equals_one_shot_allreduce():
         assert p.exitcode == 0
     for rank, results in res:
         for compress, per_step in results.items():
-            for step, (log, err, scale, tail_mean) in enumerate(per_step):
+            for step, (log, err, scale, tail_mean, _resends) in enumerate(per_step):
                 tol = 1e-5 if compress == "None" else 2 ** -7
                 assert err <= tol * max(1.0, scale), f"rank {rank} {compress} step {step}: differs from the one-shot exchange by {err:.3e}"
                 assert abs(tail_mean - 1.5) < 1e-2, "the tail (no wgrad) was not exchanged exactly once"
@@ -138,3 +154,29 @@ def test_exchange_inside_backward_equals_one_shot_allreduce():
                     assert len(early) == 2 and all(e[2] for e in early), f"rounds were not delivered during backward: {log}"
                     # 7 problems, 3 rounds: cuts after 3 and 5 queued; the two writers of layer 2's gradient are held back
                     assert sum(e[0] for e in log) == 7 and log[-1][0] >= 2
+
+
+def test_ranks_whose_graphs_differ_still_issue_the_same_collectives():
+    """the in-backward exchange must not depend on every rank queueing the same weight-gradient problems in the same
+    order.  Eight steps on two gloo ranks: in step 3 rank 1 alone drops a layer (fewer problems, fewer rounds), in step 6 both
+    ranks use a layer twice that the agreed plan knows as a single-writer region (its round is on the wire when the second
+    gradient arrives).  No step may hang, every step's arena must equal the one-shot mean, and step 6 must have exchanged the
+    planned regions a second time."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 37500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, "diverge")) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, results in res:
+        for compress, per_step in results.items():
+            assert len(per_step) == 8
+            for step, (log, err, scale, tail_mean, resends) in enumerate(per_step):
+                tol = 1e-5 if compress == "None" else 2 ** -6
+                assert err <= tol * max(1.0, scale), f"rank {rank} {compress} step {step}: differs from the one-shot exchange by {err:.3e}"
+                assert abs(tail_mean - 1.5) < 1e-2
+            assert per_step[5][4] == 0 and per_step[6][4] == 1, [s[4] for s in per_step]     # the late writer of step 6 was exchanged again

@@ -64,12 +64,15 @@ def _worker(rank, world, port, q):
     assert opt.sharded and opt.shard_len == cap // world and opt.exp_avg.numel() == cap // world
     worst_sh, worst_m = 0.0, 0.0
     for step in range(3):
-        ref.grad = sum(local_grads(step, r) for r in range(world)) / world
+        ref.grad = sum(local_grads(step, r) for r in range(world)) / world * (0.5 if step == 2 else 1.0)
         torch.nn.utils.clip_grad_norm_([ref], 1.0)       # step 0: large gradients, the clip is active; later: inactive
         ropt.step()
+        gscale = 0.5 if step == 2 else 1.0               # a caller-side gradient scale must survive the sharded step
         a.grads.copy_(local_grads(step, rank))
-        opt.set_hparams(lr=1e-2)
+        opt.set_hparams(lr=1e-2, grad_scale=gscale)
         opt.launch()
+        assert a.masters_stale is opt                    # readers of the fp32 masters are told (arena.require_fresh_masters)
+        assert abs(float(opt.hparams[8]) - gscale) < 1e-7    # ... and the device hyper-parameters hold the caller's scale again
         s, n = opt.shard_start, opt.shard_len
         lo, hi = s, min(numel, s + n)
         worst_m = max(worst_m, float((a.master[lo:hi] - ref.detach()[lo:hi]).abs().max()))
@@ -78,6 +81,7 @@ def _worker(rank, world, port, q):
     stale = float(other[:a.small_start].max())           # the other rank's big-matrix masters have not been updated ...
     small_err = float(other[a.small_start:].max())       # ... but the small tail is fresh on every rank after each step
     opt.gather_masters()
+    assert a.masters_stale is None
     gathered = float((a.master - ref.detach()).abs().max())   # ... until gathered
     m1, m2 = opt._full_moments()
     ref_state = ropt.state[ref]
@@ -105,3 +109,19 @@ def test_sharded_adamw_equals_replicated_adamw_on_two_ranks():
         assert stale > 1e-4, "the test did not exercise stale remote masters"
         assert gathered <= 2e-6, f"rank {rank}: masters after gather_masters deviate by {gathered:.3e}"
         assert merr <= 1e-6, f"rank {rank}: gathered moments deviate by {merr:.3e}"
+
+
+def test_readers_of_stale_masters_are_refused():
+    """arena.refresh (when it would really cast), dp.broadcast_params and module.state_dict() go through
+    ParamArena.require_fresh_masters: after a ZeRO-1 step it raises until gather_masters() has run (a silent recast of
+    the bf16 shadow from stale masters would revert weights on that rank)."""
+    import pytest
+    for p in (REPO, os.path.join(REPO, "simple-multimodal_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from mmfusion.arena import ParamArena
+    ns = SimpleNamespace(masters_stale=None)
+    ParamArena.require_fresh_masters(ns, "reading")      # fresh: nothing happens
+    ns.masters_stale = object()
+    with pytest.raises(RuntimeError, match="gather_masters"):
+        ParamArena.require_fresh_masters(ns, "recasting the bf16 shadow")
