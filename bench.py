@@ -330,14 +330,9 @@ def cpu_baseline_meld(model):
             "sample": f"oracle/ref_cpu.py MELD-shaped training step fp32 (dropout 0), B=16, best of 3 steps ({best * 1e3:.1f} ms/step)"}
 
 
-_SYMBOL = {"gemm4_grouped_kernel<NT,bf16>": ["gemm4_grouped_kernel<false, false, false>"],
-           "gemm2_grouped_kernel<NT,bf16>": ["gemm2_grouped_kernel<false, false, false>"],
-           "gemm5_grouped_kernel<NT,bf16>": ["gemm5_grouped_kernel<false, false, false>", "gemm5_grouped_kernel<false>"],
+_SYMBOL = {"gemm2_grouped_kernel<NT,bf16>": ["gemm2_grouped_kernel<false, false, false>"],
            "gemm2_grouped_kernel<NT,f32>": ["gemm2_grouped_kernel<false, false, true>"],
-           "gemm5_grouped_kernel<NT,f32>": ["gemm5_grouped_kernel<false, false, true>", "gemm5_grouped_kernel<true>"],
-           "gemm4_grouped_kernel<NN,bf16>": ["gemm4_grouped_kernel<false, true, false>"],
            "gemm2_grouped_kernel<NN,bf16>": ["gemm2_grouped_kernel<false, true, false>"],
-           "gemm5_grouped_kernel<NN,bf16>": ["gemm5_grouped_kernel<false, true, false>"],
            "gemm2_grouped_kernel<TN,f32>": ["gemm2_grouped_kernel<true, true, true>"],
            "gemm6_grouped_kernel<TN,f32>": ["gemm6_grouped_kernel<true, true, 32, 4, true>"],
            "gemm6_grouped_kernel<NT,bf16>": ["gemm6_grouped_kernel<false, false, 32, 4, false>"],

@@ -360,20 +360,6 @@ void attn_bwd_dq2_kernel(const AttnArgs2 a) {
 // exact in f32 (8 + 8 + 8 mantissa bits, f32 accumulate).  With D as the initial accumulator of the S (and, without
 // dropout, the dP) chain the subtraction is free:  S' = Q.K^T - LSE / scale,  p = exp2(c S');  dP' = dO.V^T - delta,
 // dS = p dP'.
-__device__ __forceinline__ bf16x8_t split3_frag(float x, bool low_half) {
-  const unsigned h = __float_as_uint(x) & 0xffff0000u;
-  const float r1 = x - __uint_as_float(h);
-  const unsigned m = __float_as_uint(r1) & 0xffff0000u;
-  const float r2 = r1 - __uint_as_float(m);
-  const unsigned l = __float_as_uint(r2) & 0xffff0000u;
-  const u32x4_t w = {low_half ? ((h >> 16) | m) : 0u, low_half ? (l >> 16) : 0u, 0u, 0u};
-  return __builtin_bit_cast(bf16x8_t, w);
-}
-__device__ __forceinline__ bf16x8_t ones3_frag(bool low_half) {
-  const u32x4_t w = {low_half ? 0x3f803f80u : 0u, low_half ? 0x00003f80u : 0u, 0u, 0u};
-  return __builtin_bit_cast(bf16x8_t, w);
-}
-
 // Sweep split as in dq2_wave: a problem with <= 32 keys gives them to waves 0 and 1, wave w works on 32-row query
 // block w of every tile; wave 1's partial dK^T, dV^T are added to wave 0's through LDS at the end.
 template <int DH, bool DROP, bool ACTIVE>
@@ -559,23 +545,69 @@ extern "C" int mmf_debug_attn2_stamps(unsigned long long* buf) {
 }
 #endif
 
+// MMF_ATTN_STUBS (build-time, measurement only; tools/build_variant.sh): MMF_ATTN_STUB bits 1 / 2 / 4 skip the forward / dQ / dK/dV
+// launches, to read off what the step's time owes to each of them (the outputs are garbage).
+#ifdef MMF_ATTN_STUBS
+static const int g_attn_stub = [] { const char* e = getenv("MMF_ATTN_STUB"); return e ? atoi(e) : 0; }();
+#else
+constexpr int g_attn_stub = 0;
+#endif
+
+// attention_narrow.hip: problems whose swept side would be walked by ONE wave (Tq <= 32 in the forward / dQ kernels, Tk <= 32 in the
+// dK/dV kernel) leave the wide launch for a kernel that splits the sweep over four independent waves.  MMF_ATTN_NARROW=0: off.
+int mmf_attn_fwd_narrowq_launch(const mmf_attn_problem* problems, const int* which, int n, int head_dim, float scale, float drop_p,
+                                const uint64_t* rng_state, uint32_t site, hipStream_t s);
+int mmf_attn_bwd_dq_narrowq_launch(const mmf_attn_problem* problems, const int* which, int n, int head_dim, float scale, float drop_p,
+                                   const uint64_t* rng_state, uint32_t site, hipStream_t s);
+int mmf_attn_bwd_dkv_narrowk_launch(const mmf_attn_problem* problems, const int* which, int n, int head_dim, float scale, float drop_p,
+                                    const uint64_t* rng_state, uint32_t site, hipStream_t s);
+static const int g_attn_narrow = [] { const char* e = getenv("MMF_ATTN_NARROW"); return e ? atoi(e) : 0; }();
+// attention3.hip: forward at one wave per SIMD (64 query rows per wave) for the problems with more than one 32-row query block
+int mmf_attn_fwd3_launch(const mmf_attn_problem* problems, const int* which, int n, int head_dim, float scale, float drop_p,
+                         const uint64_t* rng_state, uint32_t site, hipStream_t s);
+static const int g_attn_fwd_gen = [] { const char* e = getenv("MMF_ATTN_FWD_GEN"); return e ? atoi(e) : 2; }();
+
+namespace {
+struct Split { int wide[MMF_ATTN_MAX_PROBLEMS], narrow[MMF_ATTN_MAX_PROBLEMS], nw = 0, nn = 0; };
+// narrow: the swept side has more than one 32-row block to share out and the resident side is one block
+Split split_problems(const mmf_attn_problem* p, int n, bool by_keys) {
+  Split sp;
+  for (int i = 0; i < n; ++i) {
+    const int resident = by_keys ? p[i].Tk : p[i].Tq, swept = by_keys ? p[i].Tq : p[i].Tk;
+    if (g_attn_narrow && resident <= 32 && swept > 32) sp.narrow[sp.nn++] = i; else sp.wide[sp.nw++] = i;
+  }
+  return sp;
+}
+template <typename K96T, typename K96F, typename K64T, typename K64F>
+void launch4(int head_dim, bool dr, K96T k96t, K96F k96f, K64T k64t, K64F k64f, int total, const AttnArgs2& a, hipStream_t s) {
+  if (head_dim == 96) { if (dr) hipLaunchKernelGGL(k96t, dim3(total), dim3(NT), 0, s, a); else hipLaunchKernelGGL(k96f, dim3(total), dim3(NT), 0, s, a); }
+  else                { if (dr) hipLaunchKernelGGL(k64t, dim3(total), dim3(NT), 0, s, a); else hipLaunchKernelGGL(k64f, dim3(total), dim3(NT), 0, s, a); }
+}
+}  // namespace
+
 int mmf_attn_bwd2_launch(const mmf_attn_problem* problems, int n, int head_dim, float scale, float drop_p,
                          const uint64_t* rng_state, uint32_t site, hipStream_t s) {
   if (int rc = check_ranges("mmf_attn_bwd_grouped", problems, n)) return rc;
   AttnArgs2 a;
-  int total = fill_args2(a, problems, n, scale, drop_p, rng_state, site, 128, false, false);   // dQ (+ delta) first
-  const bool dr = a.drop_thresh != 0u;
-  if (head_dim == 96) { if (dr) hipLaunchKernelGGL((attn_bwd_dq2_kernel<96, true>), dim3(total), dim3(NT), 0, s, a);
-                        else    hipLaunchKernelGGL((attn_bwd_dq2_kernel<96, false>), dim3(total), dim3(NT), 0, s, a); }
-  else                { if (dr) hipLaunchKernelGGL((attn_bwd_dq2_kernel<64, true>), dim3(total), dim3(NT), 0, s, a);
-                        else    hipLaunchKernelGGL((attn_bwd_dq2_kernel<64, false>), dim3(total), dim3(NT), 0, s, a); }
-  MMF_CHECK_LAUNCH("mmf_attn_bwd_grouped(dq, v2)");
-  total = fill_args2(a, problems, n, scale, drop_p, rng_state, site, 128, true, false);        // then dK/dV (reads delta)
-  if (head_dim == 96) { if (dr) hipLaunchKernelGGL((attn_bwd_dkv2_kernel<96, true>), dim3(total), dim3(NT), 0, s, a);
-                        else    hipLaunchKernelGGL((attn_bwd_dkv2_kernel<96, false>), dim3(total), dim3(NT), 0, s, a); }
-  else                { if (dr) hipLaunchKernelGGL((attn_bwd_dkv2_kernel<64, true>), dim3(total), dim3(NT), 0, s, a);
-                        else    hipLaunchKernelGGL((attn_bwd_dkv2_kernel<64, false>), dim3(total), dim3(NT), 0, s, a); }
-  MMF_CHECK_LAUNCH("mmf_attn_bwd_grouped(dkv, v2)");
+  // dQ (+ delta) first, then dK/dV (reads delta): both dQ launches precede both dK/dV launches on the stream
+  const Split q = split_problems(problems, n, false), k = split_problems(problems, n, true);
+  if (!(g_attn_stub & 2)) {
+    if (q.nn) if (int rc = mmf_attn_bwd_dq_narrowq_launch(problems, q.narrow, q.nn, head_dim, scale, drop_p, rng_state, site, s)) return rc;
+    if (q.nw) {
+      const int total = fill_args2(a, problems, q.nw, scale, drop_p, rng_state, site, 128, false, false, q.wide);
+      launch4(head_dim, a.drop_thresh != 0u, attn_bwd_dq2_kernel<96, true>, attn_bwd_dq2_kernel<96, false>, attn_bwd_dq2_kernel<64, true>,
+              attn_bwd_dq2_kernel<64, false>, total, a, s);
+      MMF_CHECK_LAUNCH("mmf_attn_bwd_grouped(dq, v2)");
+    }
+  }
+  if (g_attn_stub & 4) return MMF_OK;
+  if (k.nn) if (int rc = mmf_attn_bwd_dkv_narrowk_launch(problems, k.narrow, k.nn, head_dim, scale, drop_p, rng_state, site, s)) return rc;
+  if (k.nw) {
+    const int total = fill_args2(a, problems, k.nw, scale, drop_p, rng_state, site, 128, true, false, k.wide);
+    launch4(head_dim, a.drop_thresh != 0u, attn_bwd_dkv2_kernel<96, true>, attn_bwd_dkv2_kernel<96, false>, attn_bwd_dkv2_kernel<64, true>,
+            attn_bwd_dkv2_kernel<64, false>, total, a, s);
+    MMF_CHECK_LAUNCH("mmf_attn_bwd_grouped(dkv, v2)");
+  }
   return MMF_OK;
 }
 
@@ -583,13 +615,21 @@ int mmf_attn_bwd2_launch(const mmf_attn_problem* problems, int n, int head_dim, 
 int mmf_attn_fwd2_launch(const mmf_attn_problem* problems, int n, int head_dim, float scale, float drop_p,
                          const uint64_t* rng_state, uint32_t site, hipStream_t s) {
   if (int rc = check_ranges("mmf_attn_fwd_grouped", problems, n)) return rc;
-  AttnArgs2 a;
-  const int total = fill_args2(a, problems, n, scale, drop_p, rng_state, site, 128, false, true);
-  const bool dr = a.drop_thresh != 0u;
-  if (head_dim == 96) { if (dr) hipLaunchKernelGGL((attn_fwd2n_kernel<96, true>), dim3(total), dim3(NT), 0, s, a);
-                        else    hipLaunchKernelGGL((attn_fwd2n_kernel<96, false>), dim3(total), dim3(NT), 0, s, a); }
-  else                { if (dr) hipLaunchKernelGGL((attn_fwd2n_kernel<64, true>), dim3(total), dim3(NT), 0, s, a);
-                        else    hipLaunchKernelGGL((attn_fwd2n_kernel<64, false>), dim3(total), dim3(NT), 0, s, a); }
-  MMF_CHECK_LAUNCH("mmf_attn_fwd_grouped");
+  if (g_attn_stub & 1) return MMF_OK;
+  Split q = split_problems(problems, n, false);
+  if (q.nn) if (int rc = mmf_attn_fwd_narrowq_launch(problems, q.narrow, q.nn, head_dim, scale, drop_p, rng_state, site, s)) return rc;
+  if (g_attn_fwd_gen == 3 && q.nw) {
+    int w3[MMF_ATTN_MAX_PROBLEMS], n3 = 0, rest = 0;
+    for (int i = 0; i < q.nw; ++i) { if (problems[q.wide[i]].Tq > 32) w3[n3++] = q.wide[i]; else q.wide[rest++] = q.wide[i]; }
+    q.nw = rest;
+    if (n3) if (int rc = mmf_attn_fwd3_launch(problems, w3, n3, head_dim, scale, drop_p, rng_state, site, s)) return rc;
+  }
+  if (q.nw) {
+    AttnArgs2 a;
+    const int total = fill_args2(a, problems, q.nw, scale, drop_p, rng_state, site, 128, false, true, q.wide);
+    launch4(head_dim, a.drop_thresh != 0u, attn_fwd2n_kernel<96, true>, attn_fwd2n_kernel<96, false>, attn_fwd2n_kernel<64, true>,
+            attn_fwd2n_kernel<64, false>, total, a, s);
+    MMF_CHECK_LAUNCH("mmf_attn_fwd_grouped");
+  }
   return MMF_OK;
 }

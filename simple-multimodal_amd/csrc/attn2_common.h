@@ -141,6 +141,22 @@ struct DkvStepD {
   }
 };
 
+// exact three-way bf16 split of an f32 value / a ones fragment: operands of the outer-product MFMA that spreads per-row statistics
+// into the accumulator layout (attention2.hip, "Row statistics of the dK/dV kernel through the matrix pipe")
+__device__ __forceinline__ bf16x8_t split3_frag(float x, bool low_half) {
+  const unsigned h = __float_as_uint(x) & 0xffff0000u;
+  const float r1 = x - __uint_as_float(h);
+  const unsigned m = __float_as_uint(r1) & 0xffff0000u;
+  const float r2 = r1 - __uint_as_float(m);
+  const unsigned l = __float_as_uint(r2) & 0xffff0000u;
+  const u32x4_t w = {low_half ? ((h >> 16) | m) : 0u, low_half ? (l >> 16) : 0u, 0u, 0u};
+  return __builtin_bit_cast(bf16x8_t, w);
+}
+__device__ __forceinline__ bf16x8_t ones3_frag(bool low_half) {
+  const u32x4_t w = {low_half ? 0x3f803f80u : 0u, low_half ? 0x00003f80u : 0u, 0u, 0u};
+  return __builtin_bit_cast(bf16x8_t, w);
+}
+
 // One wave's share of the LDS-DMA of a stage = the image (attn_helpers.h) of two 64-row tiles X (at st) and Y (at st +
 // tile bytes) of two (T, ld) matrices.  A tile is DH/8 one-KiB pieces; the stage's pieces are dealt to the 4 waves, piece
 // p = wave + 4 i, so whether piece i of a wave belongs to X or Y is a compile-time fact (DH/8 is a multiple of 4).  LDS-DMA
@@ -182,8 +198,9 @@ struct TileDma {
 namespace {
 // Work table: problems heaviest first; rows_per_wg rows of the partitioned axis (queries, or keys for the dK/dV
 // kernel) per workgroup, balanced over the chunks; workgroup ranges padded to multiples of 8 for the XCD map.
+// `which` (optional): the launch takes problems[which[0..n)]; the caller's indices stay the dropout stream ids.
 int fill_args2(AttnArgs2& a, const mmf_attn_problem* problems, int n, float scale, float drop_p, const uint64_t* rng_state,
-               uint32_t site, int rows_per_wg, bool by_keys, bool balance) {
+               uint32_t site, int rows_per_wg, bool by_keys, bool balance, const int* which = nullptr) {
   a.nprob = n; a.scale = scale;
   a.drop_thresh = (drop_p > 0.f && rng_state) ? mmf_drop_thresh(drop_p) : 0u;
   a.inv_keep = a.drop_thresh ? 1.f / (1.f - (float)a.drop_thresh * (1.f / 4294967296.f)) : 1.f;
@@ -192,7 +209,7 @@ int fill_args2(AttnArgs2& a, const mmf_attn_problem* problems, int n, float scal
   static const int split = [] { const char* e = getenv("MMF_ATTN_SPLIT"); return e ? atoi(e) : 1; }();
   a.split = split;
   int order[MMF_ATTN_MAX_PROBLEMS];
-  for (int i = 0; i < n; ++i) order[i] = i;
+  for (int i = 0; i < n; ++i) order[i] = which ? which[i] : i;
   // Launch order = longest per-workgroup chain first: a workgroup's duration is set by the length of its sweep
   // (keys for the forward / dQ kernels, queries for dK/dV), not by its row count, and the narrow problems (30
   // rows: one active wave walking the whole sweep) are pure latency chains — started first they run beside the

@@ -95,13 +95,17 @@ struct RowLoad {
       v[i] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rs, (row0 + row) * ld * 2 + ch * 16, 0, 0));
     }
   }
-  // write the rows into the wave-private slice and read them back as MFMA row fragments
-  __device__ __forceinline__ void commit(bf16x8_t (&f)[DH / 16], int lane, char* slice) const {
+  // write the rows into the wave-private slice (image of a 32-row tile)
+  __device__ __forceinline__ void store(int lane, char* slice) const {
 #pragma unroll
     for (int i = 0; i < N; ++i) {
       const int c = lane + 64 * i, row = c / CPR, ch = c % CPR;
       *reinterpret_cast<u32x4_t*>(slice + img_off<DH>(row, ch)) = v[i];
     }
+  }
+  // ... and read them back as MFMA row fragments
+  __device__ __forceinline__ void commit(bf16x8_t (&f)[DH / 16], int lane, char* slice) const {
+    store(lane, slice);
 #pragma unroll
     for (int ks = 0; ks < DH / 16; ++ks) f[ks] = row_frag<DH>(slice, 0, ks, lane);
   }

@@ -14,6 +14,7 @@
 //     hand-overs keep their piece-only vmcnt counts: with stores in flight they wait for MORE than they need, never for less —
 //     vmcnt counts loads and stores together) and drain under the next tile's k-loop.
 // NT and NN, bf16 output, every K a multiple of 32 and >= (NS + 1) * 32; everything else stays on gemm6 (gemm.hip).
+#include <algorithm>
 #include "gemm6_parts.h"
 
 namespace {
@@ -182,8 +183,15 @@ __device__ __forceinline__ void gemm7_body(const GemmArgs& args, const int total
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;                   // this wave's 128 x 128 quadrant
   const int nwg = gridDim.x;
-
-  int orig = blockIdx.x;
+  // The walk: round r hands ids r * nwg .. to the workgroups in ascending order when r is even and in DESCENDING order when it is odd.
+  // The host sorts the problems by K, longest first, so ids run from the longest tiles to the shortest; the snake gives whoever got the
+  // longest tiles of one round the shortest of the next (a static longest-processing-time deal).  With every round ascending, the in-projection
+  // dgrad launch of the text group (192 tiles of 24 k-steps, 81 of 48: 273 tiles on 256 CUs) gave its 17 second-round tiles — long ones —
+  // to workgroups 0 .. 16, four of which already held long tiles: 96 k-steps where 48 suffice (93 us in the step, 382 TF).
+  const int wid = blockIdx.x;
+  auto walk = [&](int round) { return round * nwg + ((round & 1) ? nwg - 1 - wid : wid); };
+  int round = 0;
+  int orig = walk(0);
   TileSrc ns;
   TileDst cd, nd;
   int KT, lda, ldb;
@@ -246,11 +254,11 @@ __device__ __forceinline__ void gemm7_body(const GemmArgs& args, const int total
     }
   }
 
-  bool has_next = orig + nwg < total_tiles;
+  bool has_next = walk(1) < total_tiles;
   nd = cd;
   if (has_next) {
     int la, lb;
-    locate_tile<B_KR>(args, total_tiles, orig + nwg, ns, nd, la, lb);
+    locate_tile<B_KR>(args, total_tiles, walk(1), ns, nd, la, lb);
     set_voff(voffn, la, lb);
   } else {
     ns.recA = 0; ns.recB = 0; ns.stepB = 0;
@@ -436,13 +444,14 @@ __device__ __forceinline__ void gemm7_body(const GemmArgs& args, const int total
     if constexpr (use_bias) { if (has_next) load_bias(bcur, nd); }   // the NEXT tile's bias: the drain covers the round trip
     drain_tile<CT & ~MMF_EPI_BIAS>(P, mb, nb, acc, region, lane);
     if (!has_next) break;
-    orig += nwg;
+    ++round;
+    orig = walk(round);
     cd = nd;
     KT = ns.KT;
-    has_next = orig + nwg < total_tiles;
+    has_next = walk(round + 1) < total_tiles;
     if (has_next) {
       int la, lb;
-      locate_tile<B_KR>(args, total_tiles, orig + nwg, ns, nd, la, lb);
+      locate_tile<B_KR>(args, total_tiles, walk(round + 1), ns, nd, la, lb);
       set_voff(voffn, la, lb);
     } else {
       ns.recA = 0; ns.recB = 0; ns.stepB = 0;
@@ -512,8 +521,11 @@ int mmf_gemm7_launch(const mmf_gemm_problem* problems, int num_problems, int lay
   a.site = 0u;
   a.rng_state = nullptr;
   int total = 0;
+  int order[MMF_GEMM_MAX_PROBLEMS];                            // longest reduction first (see the walk in gemm7_body)
+  for (int i = 0; i < num_problems; ++i) order[i] = i;
+  std::stable_sort(order, order + num_problems, [&](int x, int y) { return problems[x].K > problems[y].K; });
   for (int i = 0; i < num_problems; ++i) {
-    const mmf_gemm_problem& p = problems[i];
+    const mmf_gemm_problem& p = problems[order[i]];
     const size_t a_bytes = (size_t)p.M * p.lda * 2;
     const size_t b_bytes = (size_t)(layout == MMF_GEMM_NT ? p.N : p.K) * p.ldb * 2;
     const size_t c_bytes = (size_t)p.M * p.ldc * 2, x_bytes = p.aux ? (size_t)p.M * p.ldaux * 2 : 0;

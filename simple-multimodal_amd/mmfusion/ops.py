@@ -1261,9 +1261,15 @@ class _FanoutGroup(torch.autograd.Function):
             if len(live) == 1:
                 outs.append(live[0])
                 continue
-            if len(live) > lib.ADDN_MAX:
-                raise ValueError(f"fanout of {len(live)} uses (at most {lib.ADDN_MAX})")
             live = [g.contiguous() if g.dtype == BF16 else cast_to_bf16(g.contiguous()) for g in live]
+            if len(live) > lib.ADDN_MAX or live[0].numel() % 8 or any(g.data_ptr() % 16 for g in live):
+                # a gradient the grouped kernel cannot take (a view at an odd offset, an over-wide fan-out): sum this tensor's
+                # gradients with stock adds in f32 rather than raising from inside backward
+                acc = live[0].float()
+                for g in live[1:]:
+                    acc = acc + g.float()
+                outs.append(acc.to(BF16))
+                continue
             out = torch.empty_like(live[0])
             q = lib.AddNProblem()
             for k, g in enumerate(live):

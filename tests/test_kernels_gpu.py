@@ -121,8 +121,7 @@ def test_gemm_grouped_and_strided():
     assert float(out[:, 264:].float().abs().max()) == 0.0 and float(out[100:, 64:264].float().abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("layout,impl", [(GEMM_TN, 2), (GEMM_TN, 5), (GEMM_TN, 6), (GEMM_NT, 2), (GEMM_NT, 4), (GEMM_NT, 5), (GEMM_NT, 6),
-                                         (GEMM_NN, 2), (GEMM_NN, 4), (GEMM_NN, 5), (GEMM_NN, 6)])
+@pytest.mark.parametrize("layout,impl", [(GEMM_TN, 2), (GEMM_TN, 6), (GEMM_NT, 2), (GEMM_NT, 6), (GEMM_NN, 2), (GEMM_NN, 6)])
 def test_gemm_grouped_many_tiles_mixed_k(layout, impl):
     """A grouped launch big enough for the granule tile -> XCD map (mmf_xcd_tile: >= 8 x 32 tiles handed out in
     32-tile granules, the remainder as one range per XCD) with the maximum problem count and K from 16 to 2048, as in
@@ -258,8 +257,9 @@ def test_gemm7_persistent_walks_tiles_bit_identical_to_gemm6(layout, wgs):
 
 
 def test_gemm7_is_the_automatic_choice_where_it_has_the_flag_set():
-    """automatic rule: an NT / NN launch gemm6 would take (K >= 512, at least half of the CUs get a 256 x 256 tile) goes to the persistent
-    kernel when it has the launch's flag set; f32 output and flag sets it lacks stay on generation 6"""
+    """automatic rule: an NT / NN launch gemm6 would take (K a multiple of 32, at least a quarter of the CUs get a 256 x 256 tile) goes to the
+    persistent kernel when it has the launch's flag set; f32 output and flag sets it lacks stay on generation 6; smaller launches and
+    other K go to the 256 x 128 ring (generation 2); the generations that left the build are refused by name"""
     L = lib.load()
     cus = L.mmf_device_cu_count()
     rows = 256 * (cus // 3 + 1)                                   # x 3 column tiles > CUs
@@ -277,6 +277,14 @@ def test_gemm7_is_the_automatic_choice_where_it_has_the_flag_set():
     aux = bf(rnd(rows, 768, seed=3))
     ops.gemm(GEMM_NT, a, w, c, aux=aux, epilogue=EPI_MASK_AUX)     # a flag set only the NN form has
     assert L.mmf_gemm_last_impl() == 6
+    few = 256 * max(cus // 16, 1)                                  # x 3 column tiles < a quarter of the CUs
+    ops.gemm(GEMM_NT, a[:few], w, c[:few])
+    assert L.mmf_gemm_last_impl() == 2
+    a2, w2 = bf(rnd(rows, 520, seed=4)), bf(rnd(768, 520, seed=5, scale=0.05))    # K not a multiple of 32
+    ops.gemm(GEMM_NT, a2, w2, c)
+    assert L.mmf_gemm_last_impl() == 2 and rel(c, a2.float().cpu() @ w2.float().cpu().t()) < 2 ** -8
+    for gone in (1, 3, 4, 5):
+        assert L.mmf_gemm_select_impl(gone) != 0
 
 
 def test_gemm6_wgrad_reads_nothing_it_should_not_use():
@@ -426,6 +434,37 @@ def test_attention_grouped_self_packed():
         (o.sum() * (i + 1)).backward()
         assert rel(outs[i].view(B, T, d), o.detach()) < 2 ** -7
         assert rel(srcs[i].grad.view(B, T, 3 * d), r.grad) < 2e-2
+
+
+@pytest.mark.parametrize("dh", [96, 64])
+def test_attention_group_mixes_narrow_and_wide_problems(dh):
+    """One grouped call whose problems take different kernels (attention_narrow.hip: a <= 32-row side whose other side is swept is
+    split over four waves; the rest stay in the wide kernels): every output and gradient against the fp32 reference, and the
+    grouped results bit-identical to the same problems launched one by one (the split must not depend on the company)."""
+    B, H = 2, 2
+    d = H * dh
+    shapes = [(30, 200), (200, 30), (30, 30), (100, 100), (17, 333), (333, 9)]
+    def run(idxs):
+        srcs, specs = [], []
+        for n, i in enumerate(idxs):
+            Tq, Tk = shapes[i]
+            srcs += [bf(rnd(B * Tq, d, seed=50 + i)).requires_grad_(True), bf(rnd(B * Tk, 2 * d, seed=70 + i)).requires_grad_(True)]
+            specs.append(ops.AttnSpec(B, Tq, Tk, q=(2 * n, 0), k=(2 * n + 1, 0), v=(2 * n + 1, d)))
+        outs = ops.attention_group(specs, H, dh, srcs)
+        torch.autograd.backward(outs, [bf(rnd(B * shapes[i][0], d, seed=90 + i)) for i in idxs])
+        return outs, srcs
+    outs, srcs = run(range(len(shapes)))
+    for i, (Tq, Tk) in enumerate(shapes):
+        q16, kv16 = srcs[2 * i], srcs[2 * i + 1]
+        qr = q16.detach().float().cpu().view(B, Tq, d).requires_grad_(True)
+        kvr = kv16.detach().float().cpu().view(B, Tk, 2 * d).requires_grad_(True)
+        orf = attn_ref(qr, kvr[..., :d], kvr[..., d:], H)
+        orf.backward(bf(rnd(B * Tq, d, seed=90 + i)).float().cpu().view(B, Tq, d))
+        assert rel(outs[i].view(B, Tq, d), orf.detach()) < 2 ** -7, (Tq, Tk)
+        assert rel(q16.grad.view(B, Tq, d), qr.grad) < 2e-2, (Tq, Tk)
+        assert rel(kv16.grad.view(B, Tk, 2 * d), kvr.grad) < 2e-2, (Tq, Tk)
+        o1, s1 = run([i])
+        assert torch.equal(o1[0], outs[i]) and torch.equal(s1[0].grad, q16.grad) and torch.equal(s1[1].grad, kv16.grad), (Tq, Tk)
 
 
 def test_attention_online_softmax_rescale_branch():
@@ -972,3 +1011,25 @@ def test_fanout_sums_all_gradients_in_one_pass(n):
         assert torch.equal(x.grad, want.to(torch.bfloat16))        # exactly one rounding of the f32 sum
     y = bf(rnd(8, 8, seed=2))                                      # no gradient wanted: plain aliases, no node
     assert all(h is y for h in ops.fanout(y, 3))
+
+
+def test_fanout_group_sums_per_tensor_and_takes_odd_gradients():
+    """ops.fanout_group: m tensors x n handles, one grouped launch in backward (mmf_addn_grouped); a gradient the kernel cannot
+    take (a view starting at an odd element -> pointer not 16-byte aligned) is summed with stock adds instead of raising from
+    inside backward."""
+    xs = [bf(rnd(64, 40, seed=s)).requires_grad_(True) for s in (1, 2, 3)]
+    groups = ops.fanout_group(xs, 3)
+    heads, grads, want = [], [], []
+    for i, hs in enumerate(groups):
+        gs = [bf(rnd(64, 40, seed=20 + 3 * i + k)) for k in range(3)]
+        if i == 1:                                                 # the middle tensor's first gradient: storage offset 1 element
+            odd = torch.empty(64 * 40 + 1, dtype=torch.bfloat16, device=gs[0].device)[1:].view(64, 40)
+            odd.copy_(gs[0])
+            assert odd.data_ptr() % 16 != 0
+            gs[0] = odd
+        heads += hs
+        grads += gs
+        want.append(sum(g.float() for g in gs).to(torch.bfloat16))
+    torch.autograd.backward(heads, grads)
+    for x, w in zip(xs, want):
+        assert torch.equal(x.grad, w)

@@ -82,7 +82,10 @@ impls = [int(x) for x in os.environ.get("MMF_ATTN_IMPLS", "2").split(",")]
 cases = [("cross x6", cross), ("self x3", selfp), ("t<-a only", [("t", "a")]), ("a<-t only", [("a", "t")]),
          ("t<-t only", [("t", "t")]), ("v<-t only", [("v", "t")]), ("t<-v only", [("t", "v")]),
          ("big2 t<-a,a<-t", [("t", "a"), ("a", "t")]), ("narrow4 x30", [("t", "v"), ("a", "v"), ("v", "t"), ("v", "a")]),
-         ("grpA t<-a,a<-v,v<-t", [("t", "a"), ("a", "v"), ("v", "t")]), ("grpB t<-v,a<-t,v<-a", [("t", "v"), ("a", "t"), ("v", "a")])]
+         ("grpA t<-a,a<-v,v<-t", [("t", "a"), ("a", "v"), ("v", "t")]), ("grpB t<-v,a<-t,v<-a", [("t", "v"), ("a", "t"), ("v", "a")]),
+         # the launches of the two-stream step (tools/step_launches.py)
+         ("stepAV a<-t,a<-v,v<-t,v<-a", [("a", "t"), ("a", "v"), ("v", "t"), ("v", "a")]), ("stepT t<-a,t<-v", [("t", "a"), ("t", "v")]),
+         ("selfAV a<-a,v<-v", [("a", "a"), ("v", "v")])]
 if os.environ.get("MMF_ATTN_CASES"):
     want = os.environ["MMF_ATTN_CASES"].split(",")
     cases = [c for c in cases if c[0].split()[0] in want]

@@ -59,12 +59,17 @@ def main():
         ("NN dX text (l17)", GEMM_NN, [(big, 768, 3072)] * 2, EPI_ADD_AUX),
         ("NN d-out-proj text (l18)", GEMM_NN, [(big, 768, 768)] * 2, 0),
         ("NN self qkv dgrad (l15)", GEMM_NN, [(big, 768, 2304)], 0),
+        ("NN self qkv dgrad a+v (l22)", GEMM_NN, [(aud, 768, 2304), (480, 768, 2304)], 0),
+        ("NN in-proj dgrad text (l20)", GEMM_NN, [(big, 768, 768)] * 2 + [(aud, 768, 1536), (480, 768, 1536)], 0),
         ("NN in-proj dgrad a+v (l27)", GEMM_NN, [(aud, 768, 768)] * 2 + [(big, 768, 1536)] * 2 + [(480, 768, 1536)] + [(480, 768, 768)] * 2 + [(aud, 768, 1536)], 0),
     ]
     impls = [int(x) for x in os.environ.get("IMPLS", "6,7").split(",")]
     reps = int(os.environ.get("REPS", "20"))
     print(f"{'case':30s} tiles " + " ".join(f"{'g%d us' % i:>9s} {'TF':>7s}" for i in impls))
+    only = os.environ.get("ONLY")
     for name, layout, shapes, epi in cases:
+        if only and only not in name:
+            continue
         probs = make(layout, shapes, epi)
         fl = sum(2.0 * M * N * K for M, N, K in shapes)
         tiles = sum(((M + 255) // 256) * ((N + 255) // 256) for M, N, K in shapes)

@@ -42,7 +42,7 @@ def bench(layout, shapes, reps=20, epi=0, f32=False):
 def main():
     from mmfusion import lib
     L = lib.load()
-    impls = [int(x) for x in os.environ.get("IMPLS", "2,4,5").split(",")]
+    impls = [int(x) for x in os.environ.get("IMPLS", "2,6,7").split(",")]
     rows = [8192, 8192, 6400, 6400, 480, 480]
     cases = [
         ("NT 4096^3", GEMM_NT, [(4096, 4096, 4096)], 0, False),
