@@ -163,7 +163,9 @@ __device__ __forceinline__ void fwd2_wave(const AttnArgs2& a, const mmf_attn_pro
     char* oslice = smem + (ntiles & 1) * STAGE_B + wave * img_slice_bytes<DH>();
     unsigned short* Og = static_cast<unsigned short*>(P.O) + (size_t)b * Tq * P.ldo + h * DH;
     const float lt = half_sum(l);
-    store_rows_lds<DH>(o, 1.f / lt, Og, P.ldo, qs, Tq, lane, oslice);
+    int lane_e;                                            // (the lane id read again behind the sweep: see dq2_wave)
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+    store_rows_lds<DH>(o, 1.f / lt, Og, P.ldo, qs, Tq, lane_e, oslice);
     const int qrow = qs + (lane & 31);
     if (half == 0 && qrow < Tq) P.LSE[(size_t)bh * Tq + qrow] = m * LN2 + __logf(lt);
   }
@@ -323,7 +325,11 @@ __device__ __forceinline__ void dq2_wave(const AttnArgs2& a, const mmf_attn_prob
   }
   if constexpr (ACTIVE) {
     char* oslice = smem + (ntiles & 1) * STAGE_B + wave * img_slice_bytes<DH>();
-    store_rows_lds<DH>(dq[0], a.scale, static_cast<unsigned short*>(P.dQ) + qoff, P.ldq, qs, Tq, lane, oslice);
+    // the store's per-lane LDS / global offsets depend on the lane only: formed at kernel entry they are carried (spilled) around the
+    // sweep, so the lane id is read again here (guide: "recompute per block (v_mbcnt)")
+    int lane_e;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+    store_rows_lds<DH>(dq[0], a.scale, static_cast<unsigned short*>(P.dQ) + qoff, P.ldq, qs, Tq, lane_e, oslice);
     BSTAMP(7);
     BSTAMP_STORE(0);
   }
@@ -460,12 +466,15 @@ __device__ __forceinline__ void dkv2_wave(const AttnArgs2& a, const mmf_attn_pro
         s16x4_t lo[4 * DT], hi[4 * DT];
         DkvStepD<DH, QS, TD, 0>::prime(vaQ, vadO, lo, hi);  // the first fragments land under the P / dS arithmetic
         f32x16_t ds;
+        unsigned qbase = (unsigned)(q0 + 4 * half) * (unsigned)Tk + kcol;
+        if constexpr (DROP) asm volatile("" : "+v"(qbase));
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const float p = fast_exp2(s[r] * c);
           if constexpr (DROP) {
-            const unsigned q = (unsigned)(q0 + (r & 3) + 8 * (r >> 2) + 4 * half);
-            const bool keep = mmf_keep(dkey, q * (unsigned)Tk + kcol, a.drop_thresh);
+            // element index q * Tk + key as one per-block lane value + a scalar multiple of Tk: written as (q0 + c_r + 4 half) * Tk + key,
+            // hipcc hoists the sixteen (c_r + 4 half) * Tk + key out of the sweep and spills them (40 registers, reloaded every block)
+            const bool keep = mmf_keep(dkey, qbase + (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)Tk, a.drop_thresh);
             s[r] = keep ? p * a.inv_keep : 0.f;                                       // dV^T += dO^T . P_dropped
             ds[r] = p * ((keep ? dp[r] * a.inv_keep : 0.f) + dm[r]);
           } else {
@@ -508,8 +517,10 @@ __device__ __forceinline__ void dkv2_wave(const AttnArgs2& a, const mmf_attn_pro
   if constexpr (ACTIVE) {
     if (sel > 0) return;
     char* oslice = smem + (ntiles & 1) * STAGE_B + wave * img_slice_bytes<DH>();
-    store_rows_lds<DH>(dk, a.scale, static_cast<unsigned short*>(P.dK) + koff, P.ldk, k0, Tk, lane, oslice);
-    store_rows_lds<DH>(dv, 1.f, static_cast<unsigned short*>(P.dV) + voff, P.ldv, k0, Tk, lane, oslice);
+    int lane_e;                                            // (the lane id read again behind the sweep: see dq2_wave)
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+    store_rows_lds<DH>(dk, a.scale, static_cast<unsigned short*>(P.dK) + koff, P.ldk, k0, Tk, lane_e, oslice);
+    store_rows_lds<DH>(dv, 1.f, static_cast<unsigned short*>(P.dV) + voff, P.ldv, k0, Tk, lane_e, oslice);
     BSTAMP(7);
     BSTAMP_STORE(1);
   }
@@ -553,31 +564,7 @@ static const int g_attn_stub = [] { const char* e = getenv("MMF_ATTN_STUB"); ret
 constexpr int g_attn_stub = 0;
 #endif
 
-// attention_narrow.hip: problems whose swept side would be walked by ONE wave (Tq <= 32 in the forward / dQ kernels, Tk <= 32 in the
-// dK/dV kernel) leave the wide launch for a kernel that splits the sweep over four independent waves.  MMF_ATTN_NARROW=0: off.
-int mmf_attn_fwd_narrowq_launch(const mmf_attn_problem* problems, const int* which, int n, int head_dim, float scale, float drop_p,
-                                const uint64_t* rng_state, uint32_t site, hipStream_t s);
-int mmf_attn_bwd_dq_narrowq_launch(const mmf_attn_problem* problems, const int* which, int n, int head_dim, float scale, float drop_p,
-                                   const uint64_t* rng_state, uint32_t site, hipStream_t s);
-int mmf_attn_bwd_dkv_narrowk_launch(const mmf_attn_problem* problems, const int* which, int n, int head_dim, float scale, float drop_p,
-                                    const uint64_t* rng_state, uint32_t site, hipStream_t s);
-static const int g_attn_narrow = [] { const char* e = getenv("MMF_ATTN_NARROW"); return e ? atoi(e) : 0; }();
-// attention3.hip: forward at one wave per SIMD (64 query rows per wave) for the problems with more than one 32-row query block
-int mmf_attn_fwd3_launch(const mmf_attn_problem* problems, const int* which, int n, int head_dim, float scale, float drop_p,
-                         const uint64_t* rng_state, uint32_t site, hipStream_t s);
-static const int g_attn_fwd_gen = [] { const char* e = getenv("MMF_ATTN_FWD_GEN"); return e ? atoi(e) : 2; }();
-
 namespace {
-struct Split { int wide[MMF_ATTN_MAX_PROBLEMS], narrow[MMF_ATTN_MAX_PROBLEMS], nw = 0, nn = 0; };
-// narrow: the swept side has more than one 32-row block to share out and the resident side is one block
-Split split_problems(const mmf_attn_problem* p, int n, bool by_keys) {
-  Split sp;
-  for (int i = 0; i < n; ++i) {
-    const int resident = by_keys ? p[i].Tk : p[i].Tq, swept = by_keys ? p[i].Tq : p[i].Tk;
-    if (g_attn_narrow && resident <= 32 && swept > 32) sp.narrow[sp.nn++] = i; else sp.wide[sp.nw++] = i;
-  }
-  return sp;
-}
 template <typename K96T, typename K96F, typename K64T, typename K64F>
 void launch4(int head_dim, bool dr, K96T k96t, K96F k96f, K64T k64t, K64F k64f, int total, const AttnArgs2& a, hipStream_t s) {
   if (head_dim == 96) { if (dr) hipLaunchKernelGGL(k96t, dim3(total), dim3(NT), 0, s, a); else hipLaunchKernelGGL(k96f, dim3(total), dim3(NT), 0, s, a); }
@@ -589,25 +576,17 @@ int mmf_attn_bwd2_launch(const mmf_attn_problem* problems, int n, int head_dim, 
                          const uint64_t* rng_state, uint32_t site, hipStream_t s) {
   if (int rc = check_ranges("mmf_attn_bwd_grouped", problems, n)) return rc;
   AttnArgs2 a;
-  // dQ (+ delta) first, then dK/dV (reads delta): both dQ launches precede both dK/dV launches on the stream
-  const Split q = split_problems(problems, n, false), k = split_problems(problems, n, true);
   if (!(g_attn_stub & 2)) {
-    if (q.nn) if (int rc = mmf_attn_bwd_dq_narrowq_launch(problems, q.narrow, q.nn, head_dim, scale, drop_p, rng_state, site, s)) return rc;
-    if (q.nw) {
-      const int total = fill_args2(a, problems, q.nw, scale, drop_p, rng_state, site, 128, false, false, q.wide);
-      launch4(head_dim, a.drop_thresh != 0u, attn_bwd_dq2_kernel<96, true>, attn_bwd_dq2_kernel<96, false>, attn_bwd_dq2_kernel<64, true>,
-              attn_bwd_dq2_kernel<64, false>, total, a, s);
-      MMF_CHECK_LAUNCH("mmf_attn_bwd_grouped(dq, v2)");
-    }
+    const int total = fill_args2(a, problems, n, scale, drop_p, rng_state, site, 128, false, false);   // dQ (+ delta) first
+    launch4(head_dim, a.drop_thresh != 0u, attn_bwd_dq2_kernel<96, true>, attn_bwd_dq2_kernel<96, false>, attn_bwd_dq2_kernel<64, true>,
+            attn_bwd_dq2_kernel<64, false>, total, a, s);
+    MMF_CHECK_LAUNCH("mmf_attn_bwd_grouped(dq, v2)");
   }
   if (g_attn_stub & 4) return MMF_OK;
-  if (k.nn) if (int rc = mmf_attn_bwd_dkv_narrowk_launch(problems, k.narrow, k.nn, head_dim, scale, drop_p, rng_state, site, s)) return rc;
-  if (k.nw) {
-    const int total = fill_args2(a, problems, k.nw, scale, drop_p, rng_state, site, 128, true, false, k.wide);
-    launch4(head_dim, a.drop_thresh != 0u, attn_bwd_dkv2_kernel<96, true>, attn_bwd_dkv2_kernel<96, false>, attn_bwd_dkv2_kernel<64, true>,
-            attn_bwd_dkv2_kernel<64, false>, total, a, s);
-    MMF_CHECK_LAUNCH("mmf_attn_bwd_grouped(dkv, v2)");
-  }
+  const int total = fill_args2(a, problems, n, scale, drop_p, rng_state, site, 128, true, false);        // then dK/dV (reads delta)
+  launch4(head_dim, a.drop_thresh != 0u, attn_bwd_dkv2_kernel<96, true>, attn_bwd_dkv2_kernel<96, false>, attn_bwd_dkv2_kernel<64, true>,
+          attn_bwd_dkv2_kernel<64, false>, total, a, s);
+  MMF_CHECK_LAUNCH("mmf_attn_bwd_grouped(dkv, v2)");
   return MMF_OK;
 }
 
@@ -616,20 +595,10 @@ int mmf_attn_fwd2_launch(const mmf_attn_problem* problems, int n, int head_dim, 
                          const uint64_t* rng_state, uint32_t site, hipStream_t s) {
   if (int rc = check_ranges("mmf_attn_fwd_grouped", problems, n)) return rc;
   if (g_attn_stub & 1) return MMF_OK;
-  Split q = split_problems(problems, n, false);
-  if (q.nn) if (int rc = mmf_attn_fwd_narrowq_launch(problems, q.narrow, q.nn, head_dim, scale, drop_p, rng_state, site, s)) return rc;
-  if (g_attn_fwd_gen == 3 && q.nw) {
-    int w3[MMF_ATTN_MAX_PROBLEMS], n3 = 0, rest = 0;
-    for (int i = 0; i < q.nw; ++i) { if (problems[q.wide[i]].Tq > 32) w3[n3++] = q.wide[i]; else q.wide[rest++] = q.wide[i]; }
-    q.nw = rest;
-    if (n3) if (int rc = mmf_attn_fwd3_launch(problems, w3, n3, head_dim, scale, drop_p, rng_state, site, s)) return rc;
-  }
-  if (q.nw) {
-    AttnArgs2 a;
-    const int total = fill_args2(a, problems, q.nw, scale, drop_p, rng_state, site, 128, false, true, q.wide);
-    launch4(head_dim, a.drop_thresh != 0u, attn_fwd2n_kernel<96, true>, attn_fwd2n_kernel<96, false>, attn_fwd2n_kernel<64, true>,
-            attn_fwd2n_kernel<64, false>, total, a, s);
-    MMF_CHECK_LAUNCH("mmf_attn_fwd_grouped");
-  }
+  AttnArgs2 a;
+  const int total = fill_args2(a, problems, n, scale, drop_p, rng_state, site, 128, false, true);
+  launch4(head_dim, a.drop_thresh != 0u, attn_fwd2n_kernel<96, true>, attn_fwd2n_kernel<96, false>, attn_fwd2n_kernel<64, true>,
+          attn_fwd2n_kernel<64, false>, total, a, s);
+  MMF_CHECK_LAUNCH("mmf_attn_fwd_grouped");
   return MMF_OK;
 }

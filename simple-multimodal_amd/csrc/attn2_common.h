@@ -198,9 +198,8 @@ struct TileDma {
 namespace {
 // Work table: problems heaviest first; rows_per_wg rows of the partitioned axis (queries, or keys for the dK/dV
 // kernel) per workgroup, balanced over the chunks; workgroup ranges padded to multiples of 8 for the XCD map.
-// `which` (optional): the launch takes problems[which[0..n)]; the caller's indices stay the dropout stream ids.
 int fill_args2(AttnArgs2& a, const mmf_attn_problem* problems, int n, float scale, float drop_p, const uint64_t* rng_state,
-               uint32_t site, int rows_per_wg, bool by_keys, bool balance, const int* which = nullptr) {
+               uint32_t site, int rows_per_wg, bool by_keys, bool balance) {
   a.nprob = n; a.scale = scale;
   a.drop_thresh = (drop_p > 0.f && rng_state) ? mmf_drop_thresh(drop_p) : 0u;
   a.inv_keep = a.drop_thresh ? 1.f / (1.f - (float)a.drop_thresh * (1.f / 4294967296.f)) : 1.f;
@@ -209,7 +208,7 @@ int fill_args2(AttnArgs2& a, const mmf_attn_problem* problems, int n, float scal
   static const int split = [] { const char* e = getenv("MMF_ATTN_SPLIT"); return e ? atoi(e) : 1; }();
   a.split = split;
   int order[MMF_ATTN_MAX_PROBLEMS];
-  for (int i = 0; i < n; ++i) order[i] = which ? which[i] : i;
+  for (int i = 0; i < n; ++i) order[i] = i;
   // Launch order = longest per-workgroup chain first: a workgroup's duration is set by the length of its sweep
   // (keys for the forward / dQ kernels, queries for dK/dV), not by its row count, and the narrow problems (30
   // rows: one active wave walking the whole sweep) are pure latency chains — started first they run beside the

@@ -136,7 +136,7 @@ def test_row_linear_folds_cast_dropout_and_relu_gradient(relu, f32_in, p):
 
 
 @pytest.mark.parametrize("B,H,dh,Tq,Tk", [(2, 2, 96, 70, 40), (1, 2, 64, 33, 150), (2, 1, 96, 130, 96),
-                                          (1, 2, 96, 30, 150), (2, 1, 96, 130, 30), (1, 2, 64, 20, 100)])   # one narrow side: attention_narrow.hip
+                                          (1, 2, 96, 30, 150), (2, 1, 96, 130, 30), (1, 2, 64, 20, 100)])   # one narrow side
 def test_attention_dropout_matches_reference_given_the_mask(B, H, dh, Tq, Tk):
     """P_dropped is read out by making V a shifted identity; fwd and bwd are then checked with that mask"""
     p, d = 0.2, H * dh

@@ -438,9 +438,9 @@ def test_attention_grouped_self_packed():
 
 @pytest.mark.parametrize("dh", [96, 64])
 def test_attention_group_mixes_narrow_and_wide_problems(dh):
-    """One grouped call whose problems take different kernels (attention_narrow.hip: a <= 32-row side whose other side is swept is
-    split over four waves; the rest stay in the wide kernels): every output and gradient against the fp32 reference, and the
-    grouped results bit-identical to the same problems launched one by one (the split must not depend on the company)."""
+    """One grouped call of problems with a <= 32-row side on either end beside wide ones (MulT's 30-frame stream against 512 / 400
+    positions): every output and gradient against the fp32 reference, and the grouped results bit-identical to the same problems
+    launched one by one (a problem's arithmetic must not depend on its company in the launch)."""
     B, H = 2, 2
     d = H * dh
     shapes = [(30, 200), (200, 30), (30, 30), (100, 100), (17, 333), (333, 9)]

@@ -1,10 +1,10 @@
 #!/bin/bash
 # Per-KERNEL durations of the attention launches of chosen tools/attn_bench.py cases (plain launches under rocprofv3 --kernel-trace):
-#   CASES="stepAV,a<-t" bash tools/attn_kernel_times.sh   -> gpurun_out/attn_kt/<case>_<narrow>.txt
+#   CASES="stepAV,a<-t" bash tools/attn_kernel_times.sh
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; cd $R
 O=gpurun_out/${TAG:-attn_kt}; mkdir -p $O
-for nar in ${NARROW:-0 1}; do
+for nar in 0; do
   for c in ${CASES//,/ }; do
     d=$O/trace_${c//[<>-]/_}_$nar
     MMF_ATTN_NARROW=$nar MMF_ATTN_NOGRAPH=1 MMF_ATTN_CASES="$c" timeout -k 10 120 rocprofv3 --kernel-trace --stats -d $d --output-format csv -- python3 tools/attn_bench.py ${WHAT:-bwd} > $O/log_${c//[<>-]/_}_$nar.txt 2>&1
