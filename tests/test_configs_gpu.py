@@ -21,7 +21,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from helpers import l2_rel  # noqa: E402
+from helpers import l2_rel, relu_agreement  # noqa: E402
 from mmfusion import synth  # noqa: E402
 from oracle import ref_cpu  # noqa: E402
 from test_parity_gpu import GIN_L2, GP_L2, GP_L2_RELU, OUT_ATOL, RELU_FED  # noqa: E402
@@ -114,12 +114,13 @@ def test_hier_seq_matches_oracle(name, B, Ts, d, H):
         want = ref_b[k].detach()
         assert l2_rel(out[k], want) <= OUT_BF16, f"{name}: {k} vs bf16-storage oracle rel L2 {l2_rel(out[k], want):.3e}"
     relu_out = ["early_features", "mult_features", "contrastive_features", "adaptive_features"]
-    agree = {k: ((out[k].detach().float().cpu() > 0) == (ref_b[k].detach() > 0)).float() for k in relu_out}
-    agree["meta_hidden"] = ((cap_hip["meta_hidden"].float().cpu() > 0) == (cap_ref["meta_hidden"] > 0)).float()
-    nflip = sum(int((1 - a).sum()) for a in agree.values())
+    agree, nflip, bound = {}, 0, 0
+    for k in relu_out + ["meta_hidden"]:
+        g_, w_ = (cap_hip[k], cap_ref[k]) if k == "meta_hidden" else (out[k], ref_b[k])
+        agree[k], n_, b_ = relu_agreement(g_, w_, f"{name}: {k}")      # per tensor: flips bounded by that tensor's oracle units near zero
+        nflip, bound = nflip + n_, bound + b_
     nunit = sum(a.numel() for a in agree.values())
-    print(f"hier-seq {name}: {nflip} of {nunit} top-level ReLU units differ in state from the bf16-storage oracle")
-    assert nflip <= max(2, int(3e-3 * nunit)), f"{name}: {nflip} of {nunit} top-level ReLU units flipped"      # measured 0.05 % (config 3)
+    print(f"hier-seq {name}: {nflip} of {nunit} top-level ReLU units differ in state from the bf16-storage oracle (bound {bound})")
     Pm = {k: v.detach().clone().requires_grad_(True) for k, v in P.items()}
     xm = [x.clone().requires_grad_(True) for x in xs]
     with ref_cpu.bf16_storage():

@@ -11,7 +11,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from golden_cases import CASES  # noqa: E402
-from helpers import (cfg_from_meta, fixture_inputs, fixture_params, l2_rel, load_fixture, oracle_fwd_bwd,
+from helpers import (cfg_from_meta, fixture_inputs, fixture_params, l2_rel, load_fixture, oracle_fwd_bwd, relu_agreement,
                      rel_err)  # noqa: E402
 from mmfusion import synth  # noqa: E402
 
@@ -188,10 +188,9 @@ def test_mult_at_the_bench_configuration_matches_oracle():
         ref_b0 = ref_cpu.multimodal_transformer({k: v.detach() for k, v in P.items()}, "", *xs, S["heads"])
     for k, want in ref_b0.items():                       # forward against the bf16-storage oracle
         assert l2_rel(out[k], want) <= OUT_BF16, f"{k} vs bf16-storage oracle rel L2 {l2_rel(out[k], want):.3e}"
-    agree = ((out["fused_features"].detach().float().cpu() > 0) == (ref_b0["fused_features"] > 0)).float()
-    nflip = int((1 - agree).sum())
-    print(f"bench config: {nflip} of {agree.numel()} fused_features units differ in ReLU state from the bf16-storage oracle")
-    assert nflip <= max(2, int(3e-3 * agree.numel())), f"{nflip} of {agree.numel()} top-level ReLU units flipped"      # measured 0.17 %
+    agree, nflip, bound = relu_agreement(out["fused_features"], ref_b0["fused_features"], "fused_features")
+    print(f"bench config: {nflip} of {agree.numel()} fused_features units differ in ReLU state from the bf16-storage oracle "
+          f"(bound from the oracle's pre-activations near zero: {bound})")
 
     def masked(o, mask):
         o = dict(o)
