@@ -11,13 +11,43 @@ namespace {
 
 constexpr int OPT_THREADS = 256;
 
+#ifndef MMF_OPT_UNROLL
+#define MMF_OPT_UNROLL 2          // 16-byte vectors per thread and stream in flight per iteration
+#endif
+#ifndef MMF_OPT_NT
+#define MMF_OPT_NT 1              // non-temporal loads / stores for what the step touches once (masters, moments, gradients)
+#endif
+template <typename T> __device__ __forceinline__ T ld_stream(const T* p) {
+#if MMF_OPT_NT
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
+template <typename T> __device__ __forceinline__ void st_stream(T* p, const T& v) {
+#if MMF_OPT_NT
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
+
 __global__ __launch_bounds__(OPT_THREADS)
 void sqnorm_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
   __shared__ float red[OPT_THREADS / 64];
+  constexpr int U = 2 * MMF_OPT_UNROLL;
   const int64_t nvec = n >> 2;
   const int64_t stride = (int64_t)gridDim.x * OPT_THREADS;
   float s = 0.f;
-  for (int64_t i = (int64_t)blockIdx.x * OPT_THREADS + threadIdx.x; i < nvec; i += stride) {
+  int64_t i = (int64_t)blockIdx.x * OPT_THREADS + threadIdx.x;
+  for (; i + (U - 1) * stride < nvec; i += U * stride) {     // U loads in flight per thread
+    f32x4_t v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = *reinterpret_cast<const f32x4_t*>(x + (i + u * stride) * 4);
+#pragma unroll
+    for (int u = 0; u < U; ++u) s += v[u][0] * v[u][0] + v[u][1] * v[u][1] + v[u][2] * v[u][2] + v[u][3] * v[u][3];
+  }
+  for (; i < nvec; i += stride) {
     const f32x4_t v = *reinterpret_cast<const f32x4_t*>(x + i * 4);
     s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
   }
@@ -46,11 +76,7 @@ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __r
   const float step = lr / bc1, rs2 = rsqrtf(bc2), decay = 1.f - lr * wd;
   const int64_t nvec = n >> 2;
   const int64_t stride = (int64_t)gridDim.x * OPT_THREADS;
-  for (int64_t i = (int64_t)blockIdx.x * OPT_THREADS + threadIdx.x; i < nvec; i += stride) {
-    f32x4_t pp = *reinterpret_cast<const f32x4_t*>(p + i * 4);
-    const f32x4_t gg = *reinterpret_cast<const f32x4_t*>(g + i * 4);
-    f32x4_t mm = *reinterpret_cast<const f32x4_t*>(m + i * 4);
-    f32x4_t vv = *reinterpret_cast<const f32x4_t*>(v + i * 4);
+  auto update = [&](f32x4_t& pp, const f32x4_t& gg, f32x4_t& mm, f32x4_t& vv) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float ge = gg[e] * gs;
@@ -58,6 +84,36 @@ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __r
       vv[e] = b2 * vv[e] + (1.f - b2) * ge * ge;
       pp[e] = pp[e] * decay - step * mm[e] / (sqrtf(vv[e]) * rs2 + eps);
     }
+  };
+  constexpr int U = MMF_OPT_UNROLL;
+  int64_t i = (int64_t)blockIdx.x * OPT_THREADS + threadIdx.x;
+  for (; i + (U - 1) * stride < nvec; i += U * stride) {      // 4 U loads in flight per thread before the first use
+    f32x4_t pp[U], gg[U], mm[U], vv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t o = (i + u * stride) * 4;
+      pp[u] = ld_stream(reinterpret_cast<const f32x4_t*>(p + o));
+      gg[u] = ld_stream(reinterpret_cast<const f32x4_t*>(g + o));
+      mm[u] = ld_stream(reinterpret_cast<const f32x4_t*>(m + o));
+      vv[u] = ld_stream(reinterpret_cast<const f32x4_t*>(v + o));
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t o = (i + u * stride) * 4;
+      update(pp[u], gg[u], mm[u], vv[u]);
+      st_stream(reinterpret_cast<f32x4_t*>(p + o), pp[u]);
+      st_stream(reinterpret_cast<f32x4_t*>(m + o), mm[u]);
+      st_stream(reinterpret_cast<f32x4_t*>(v + o), vv[u]);
+      const u32x2_t sh = {pack_bf16x2(pp[u][0], pp[u][1]), pack_bf16x2(pp[u][2], pp[u][3])};
+      *reinterpret_cast<u32x2_t*>(shadow + o) = sh;              // the next forward's GEMMs read the shadow: plain store
+    }
+  }
+  for (; i < nvec; i += stride) {
+    f32x4_t pp = *reinterpret_cast<const f32x4_t*>(p + i * 4);
+    const f32x4_t gg = *reinterpret_cast<const f32x4_t*>(g + i * 4);
+    f32x4_t mm = *reinterpret_cast<const f32x4_t*>(m + i * 4);
+    f32x4_t vv = *reinterpret_cast<const f32x4_t*>(v + i * 4);
+    update(pp, gg, mm, vv);
     *reinterpret_cast<f32x4_t*>(p + i * 4) = pp;
     *reinterpret_cast<f32x4_t*>(m + i * 4) = mm;
     *reinterpret_cast<f32x4_t*>(v + i * 4) = vv;
