@@ -92,10 +92,12 @@ void skinny_fwd_kernel(const SkinnyArgs a) {
 #pragma unroll
   for (int t = 0; t < MAX_MT; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   const int wrow = n0 + (lane & 15), kc = (lane >> 4) << 3;
-  bf16x8_t wf, xf[MAX_MT], wn_, xn_[MAX_MT];
-  auto fetch = [&](int s, bf16x8_t& w, bf16x8_t (&x)[MAX_MT]) {
+  // A wave's steps form a latency chain (few workgroups, one wave per SIMD at most): THREE steps' fragments are in flight, each requested
+  // two steps before its MFMAs.  Round 2-3 kept one step ahead: a 3840-deep reduction (the meta MLP: 15 steps per wave) then paid ~1.5 us per step.
+  struct Frags { bf16x8_t w, x[MAX_MT]; };
+  auto fetch = [&](int s, Frags& f) {
     const int k = (s << 5) + kc;
-    w = load_frag_rows(W, P.ldw, wrow, N, k, K);
+    f.w = load_frag_rows(W, P.ldw, wrow, N, k, K);
 #pragma unroll
     for (int t = 0; t < MAX_MT; ++t)
       if (t < mt) {
@@ -103,23 +105,28 @@ void skinny_fwd_kernel(const SkinnyArgs a) {
           float v[8];
           const int m = t * 16 + (lane & 15);
           load8_f32(P.X, true, P.ldx, m, M, k, K, v);
-          x[t] = pack8(v);
+          f.x[t] = pack8(v);
           if (x16 && n0 == 0 && m < M && k < K)              // the first strip's workgroup leaves the bf16 copy behind (wgrad operand)
-            *reinterpret_cast<u32x4_t*>(x16 + (size_t)m * a.lddz[pi] + k) = __builtin_bit_cast(u32x4_t, x[t]);
+            *reinterpret_cast<u32x4_t*>(x16 + (size_t)m * a.lddz[pi] + k) = __builtin_bit_cast(u32x4_t, f.x[t]);
         } else {
-          x[t] = load_frag_rows(X, P.ldx, t * 16 + (lane & 15), M, k, K);
+          f.x[t] = load_frag_rows(X, P.ldx, t * 16 + (lane & 15), M, k, K);
         }
       }
   };
-  if (s0 < s1) fetch(s0, wf, xf);
-  for (int s = s0; s < s1; ++s) {
-    if (s + 1 < s1) fetch(s + 1, wn_, xn_);
+  auto use = [&](const Frags& f) {
 #pragma unroll
     for (int t = 0; t < MAX_MT; ++t)
-      if (t < mt) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[t], acc[t], 0, 0, 0);
-    wf = wn_;
-#pragma unroll
-    for (int t = 0; t < MAX_MT; ++t) xf[t] = xn_[t];
+      if (t < mt) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.w, f.x[t], acc[t], 0, 0, 0);
+  };
+  Frags f0, f1, f2;
+  if (s0 < s1) fetch(s0, f0);
+  if (s0 + 1 < s1) fetch(s0 + 1, f1);
+  if (s0 + 2 < s1) fetch(s0 + 2, f2);
+  for (int s = s0; s < s1; s += 3) {
+    use(f0);
+    if (s + 3 < s1) fetch(s + 3, f0);
+    if (s + 1 < s1) { use(f1); if (s + 4 < s1) fetch(s + 4, f1); }
+    if (s + 2 < s1) { use(f2); if (s + 5 < s1) fetch(s + 5, f2); }
   }
   if (wave > 0) {
 #pragma unroll
@@ -196,23 +203,23 @@ void skinny_dgrad_kernel(const SkinnyArgs a) {
 #pragma unroll
     for (int t = 0; t < MAX_MT; ++t) acc[c][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
-  u32x4_t stage[CT];
-  bf16x8_t yf[MAX_MT], yn_[MAX_MT];
-  auto fetch = [&](int s, bf16x8_t (&y)[MAX_MT]) {                       // 32 x 16 CT block of W (16-B chunks, coalesced) + dy
+  // three steps in flight per wave, as in the forward (a 3072-row W strip is 12 steps per wave: 30 -> 10 us for GraphFusion's dgrads)
+  struct Block { u32x4_t stage[CT]; bf16x8_t y[MAX_MT]; };
+  auto fetch = [&](int s, Block& bk) {                                   // 32 x 16 CT block of W (16-B chunks, coalesced) + dy
     const int r0 = s << 5;
 #pragma unroll
     for (int i = 0; i < CT; ++i) {
       const int ch = lane + 64 * i, row = ch / (2 * CT), col = (ch % (2 * CT)) << 3;
       u32x4_t v = {0u, 0u, 0u, 0u};
       if (r0 + row < Nout && c0 + col < Kin) v = *reinterpret_cast<const u32x4_t*>(W + (size_t)(r0 + row) * P.ldw + c0 + col);
-      stage[i] = v;
+      bk.stage[i] = v;
     }
 #pragma unroll
     for (int t = 0; t < MAX_MT; ++t)
       if (t < mt) {
         const int m = t * 16 + (lane & 15), n = r0 + (g << 3);
         if (!gated) {
-          y[t] = load_frag_rows(dY, P.ldx, m, M, n, Nout);
+          bk.y[t] = load_frag_rows(dY, P.ldx, m, M, n, Nout);
         } else {
           // dz = dy * (gate > 0) * gate_scale [* keep / (1 - p)], narrowed to bf16: the ReLU / dropout gradient and the casts
           // around it happen while the fragment is loaded; the first strip's workgroup also writes dz out (wgrad operand)
@@ -228,20 +235,18 @@ void skinny_dgrad_kernel(const SkinnyArgs a) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = mmf_keep(drop_key, idx + e, a.drop_thresh) ? v[e] * a.drop_scale : 0.f;
           }
-          y[t] = pack8(v);
+          bk.y[t] = pack8(v);
           if (dz && c0 == 0 && m < M && n < Nout)
-            *reinterpret_cast<u32x4_t*>(dz + (size_t)m * a.lddz[pi] + n) = __builtin_bit_cast(u32x4_t, y[t]);
+            *reinterpret_cast<u32x4_t*>(dz + (size_t)m * a.lddz[pi] + n) = __builtin_bit_cast(u32x4_t, bk.y[t]);
         }
       }
   };
-  if (s0 < s1) fetch(s0, yf);
-  for (int s = s0; s < s1; ++s) {
+  auto use = [&](const Block& bk) {
 #pragma unroll
     for (int i = 0; i < CT; ++i) {
       const int ch = lane + 64 * i, row = ch / (2 * CT), col = (ch % (2 * CT)) << 3;
-      *reinterpret_cast<u32x4_t*>(slice + row * SB + col * 2) = stage[i];
+      *reinterpret_cast<u32x4_t*>(slice + row * SB + col * 2) = bk.stage[i];
     }
-    if (s + 1 < s1) fetch(s + 1, yn_);                                   // next block in flight under the MFMAs
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
       // W^T fragment: lane (i = k_in column c*16 + (l & 15), k = n_out 8g + e) from rows 8g .. 8g+7 of the slice
@@ -252,10 +257,18 @@ void skinny_dgrad_kernel(const SkinnyArgs a) {
       const bf16x8_t wf = __builtin_bit_cast(bf16x8_t, wv);
 #pragma unroll
       for (int t = 0; t < MAX_MT; ++t)
-        if (t < mt) acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, yf[t], acc[c][t], 0, 0, 0);
+        if (t < mt) acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, bk.y[t], acc[c][t], 0, 0, 0);
     }
-#pragma unroll
-    for (int t = 0; t < MAX_MT; ++t) yf[t] = yn_[t];
+  };
+  Block b0, b1, b2;
+  if (s0 < s1) fetch(s0, b0);
+  if (s0 + 1 < s1) fetch(s0 + 1, b1);
+  if (s0 + 2 < s1) fetch(s0 + 2, b2);
+  for (int s = s0; s < s1; s += 3) {
+    use(b0);
+    if (s + 3 < s1) fetch(s + 3, b0);
+    if (s + 1 < s1) { use(b1); if (s + 4 < s1) fetch(s + 4, b1); }
+    if (s + 2 < s1) { use(b2); if (s + 5 < s1) fetch(s + 5, b2); }
   }
   __syncthreads();                                                       // slices are dead: reuse LDS for the sums
   float* red = reinterpret_cast<float*>(smem);                           // [7 waves][CT c][MAX_MT][64 lanes][4]

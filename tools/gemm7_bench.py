@@ -39,6 +39,25 @@ def time_impl(L, impl, layout, probs, epi, reps):
     return e0.elapsed_time(e1) * 1e3 / reps
 
 
+def time_cold(L, impl, layout, probs, epi, reps, flush):
+    """one launch at a time between events; flush: a 1 GiB fill in front of every launch (L2 and Infinity Cache hold nothing of the operands)"""
+    lib.check(L.mmf_gemm_select_impl(impl))
+    junk = torch.empty(1 << 28, device=DEV, dtype=torch.float32) if flush else None
+    tot = 0.0
+    for _ in range(reps):
+        if flush:
+            junk.fill_(1.0)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        ops.gemm_group(layout, probs, epi)
+        e1.record()
+        torch.cuda.synchronize()
+        tot += e0.elapsed_time(e1) * 1e3
+    lib.check(L.mmf_gemm_select_impl(0))
+    return tot / reps
+
+
 def main():
     L = lib.load()
     big, aud = 8192, 6400
@@ -77,7 +96,11 @@ def main():
         for _ in range(3):                                         # interleaved rounds, best of three
             for i in impls:
                 best[i] = min(best[i], time_impl(L, i, layout, probs, epi, reps))
-        print(f"{name:30s} {tiles:5d} " + " ".join(f"{best[i]:9.1f} {fl / best[i] / 1e6:7.0f}" for i in impls), flush=True)
+        row = f"{name:30s} {tiles:5d} " + " ".join(f"{best[i]:9.1f} {fl / best[i] / 1e6:7.0f}" for i in impls)
+        if os.environ.get("COLD"):                                 # single launches: operands warm / flushed out of the caches
+            row += "   single warm " + " ".join(f"{time_cold(L, i, layout, probs, epi, 8, False):7.1f}" for i in impls)
+            row += "   single cold " + " ".join(f"{time_cold(L, i, layout, probs, epi, 8, True):7.1f}" for i in impls)
+        print(row, flush=True)
         del probs
         torch.cuda.empty_cache()
 
