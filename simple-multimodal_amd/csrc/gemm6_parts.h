@@ -19,6 +19,7 @@ struct GemmArgs {
   unsigned drop_thresh, site;        // MMF_EPI_DROPOUT
   const unsigned long long* rng_state;
   int tile_start[MMF_GEMM_MAX_PROBLEMS + 1];
+  short orig[MMF_GEMM_MAX_PROBLEMS];   // gemm7: the caller's index of problem i (its problems are sorted by K; the dropout stream id is the caller's)
   mmf_gemm_problem p[MMF_GEMM_MAX_PROBLEMS];
 };
 

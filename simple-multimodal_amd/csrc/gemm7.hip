@@ -85,9 +85,14 @@ __device__ __forceinline__ void locate_tile(const GemmArgs& args, const int tota
 // CT: the epilogue's flag set (compile time; alpha = 1, no dropout).  The bias is not added here: it is what the tile's accumulators
 // START from (bias_init below).
 template <int CT>
-__device__ __forceinline__ void drain_tile(const mmf_gemm_problem& P, const int mb, const int nb, f32x16_t (&acc)[4][4],
-                                           char* region, const int lane) {
+__device__ __forceinline__ void drain_tile(const GemmArgs& args, const int pi, const mmf_gemm_problem& P, const int mb, const int nb,
+                                           f32x16_t (&acc)[4][4], char* region, const int lane) {
   constexpr bool AUX = (CT & (MMF_EPI_MASK_AUX | MMF_EPI_ADD_AUX)) != 0;
+  constexpr bool DROP = (CT & MMF_EPI_DROPOUT) != 0;
+  // dropout on the (activated) outputs, the mask of gemm6's epilogue: element m * N + n of the caller's problem `orig[pi]`
+  const unsigned drop_key = DROP ? mmf_rng_key(*args.rng_state, args.site, (unsigned)args.orig[pi]) : 0u;
+  const float drop_scale = DROP ? 1.f / (1.f - (float)args.drop_thresh * (1.f / 4294967296.f)) : 1.f;
+  const float alpha = (CT & MMF_EPI_MASK_AUX) ? args.alpha : 1.f;            // 1 / (1 - p) of a dropout backward rides on the ReLU mask
   const int r = lane & 31, h = lane >> 5, q = lane >> 4, cq = lane & 15;
   // region offsets: accumulator layout (8 bytes at chunk c = 4 tn + g, half h, of row r), whole-row layout (16-byte chunk cq of row 4 it + q)
   const unsigned wr_base = (unsigned)(r * 256 + 8 * h + 16 * (r & 15));
@@ -139,12 +144,17 @@ __device__ __forceinline__ void drain_tile(const mmf_gemm_problem& P, const int 
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
         }
+        if constexpr (DROP) {
+          const unsigned idx = (unsigned)(mb + 32 * tm + r) * (unsigned)P.N + (unsigned)(nb + 32 * tn + 8 * g + 4 * h);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = mmf_keep(drop_key, idx + e, args.drop_thresh) ? v[e] * drop_scale : 0.f;
+        }
         if constexpr (AUX) {
           const u32x2_t a = axv[tn][g];
           const float a0 = bf16lo(a[0]), a1 = bf16hi(a[0]), a2 = bf16lo(a[1]), a3 = bf16hi(a[1]);
           if constexpr (CT & MMF_EPI_MASK_AUX) {
-            v[0] = a0 > 0.f ? v[0] : 0.f; v[1] = a1 > 0.f ? v[1] : 0.f;
-            v[2] = a2 > 0.f ? v[2] : 0.f; v[3] = a3 > 0.f ? v[3] : 0.f;
+            v[0] = a0 > 0.f ? v[0] * alpha : 0.f; v[1] = a1 > 0.f ? v[1] * alpha : 0.f;
+            v[2] = a2 > 0.f ? v[2] * alpha : 0.f; v[3] = a3 > 0.f ? v[3] * alpha : 0.f;
           } else {
             v[0] += a0; v[1] += a1; v[2] += a2; v[3] += a3;
           }
@@ -442,7 +452,7 @@ __device__ __forceinline__ void gemm7_body(const GemmArgs& args, const int total
     const mmf_gemm_problem& P = args.p[cd.pi];
     const int mb = cd.m0 + 128 * wm, nb = cd.n0 + 128 * wn;
     if constexpr (use_bias) { if (has_next) load_bias(bcur, nd); }   // the NEXT tile's bias: the drain covers the round trip
-    drain_tile<CT & ~MMF_EPI_BIAS>(P, mb, nb, acc, region, lane);
+    drain_tile<CT & ~MMF_EPI_BIAS>(args, cd.pi, P, mb, nb, acc, region, lane);
     if (!has_next) break;
     ++round;
     orig = walk(round);
@@ -481,6 +491,10 @@ bool launch7_select(int layout, int eflags, const GemmArgs* a, int total, int gr
     if (eflags == MMF_EPI_BIAS)                           { if (a) launch7<false, MMF_EPI_BIAS>(*a, total, grid, s); return true; }
     if (eflags == (MMF_EPI_BIAS | MMF_EPI_RELU))          { if (a) launch7<false, MMF_EPI_BIAS | MMF_EPI_RELU>(*a, total, grid, s); return true; }
     if (eflags == (MMF_EPI_BIAS | MMF_EPI_ADD_AUX))       { if (a) launch7<false, MMF_EPI_BIAS | MMF_EPI_ADD_AUX>(*a, total, grid, s); return true; }
+    if (eflags == (MMF_EPI_BIAS | MMF_EPI_RELU | MMF_EPI_DROPOUT)) {       // FFN hidden layer in training mode
+      if (a) launch7<false, MMF_EPI_BIAS | MMF_EPI_RELU | MMF_EPI_DROPOUT>(*a, total, grid, s);
+      return true;
+    }
   } else if (layout == MMF_GEMM_NN) {
     if (eflags == 0)                                      { if (a) launch7<true, 0>(*a, total, grid, s); return true; }
     if (eflags == MMF_EPI_MASK_AUX)                       { if (a) launch7<true, MMF_EPI_MASK_AUX>(*a, total, grid, s); return true; }
@@ -499,7 +513,9 @@ extern "C" int mmf_gemm_set_persistent_workgroups(int n) {
 
 // whether the persistent kernel can take this launch (gemm.hip asks before selecting it)
 bool mmf_gemm7_supports(const mmf_gemm_problem* problems, int num_problems, int layout, int epilogue, int out_f32, const mmf_gemm_extra* extra) {
-  if (out_f32 || (extra && extra->alpha != 1.f) || !launch7_select(layout, epilogue, nullptr, 0, 0, nullptr)) return false;
+  if (out_f32 || !launch7_select(layout, epilogue, nullptr, 0, 0, nullptr)) return false;
+  if (extra && extra->alpha != 1.f && !(layout == MMF_GEMM_NN && epilogue == MMF_EPI_MASK_AUX)) return false;   // alpha rides on the mask only
+  if ((epilogue & MMF_EPI_DROPOUT) && !(extra && extra->rng_state)) return false;
   for (int i = 0; i < num_problems; ++i) {
     const mmf_gemm_problem& p = problems[i];
     if (p.K % BK || p.K < (NS + 1) * BK || (p.N & 7) || (p.ldc & 7) || (p.aux && (p.ldaux & 7))) return false;
@@ -511,15 +527,15 @@ int mmf_gemm7_launch(const mmf_gemm_problem* problems, int num_problems, int lay
                      int out_f32, const mmf_gemm_extra* extra, hipStream_t s) {
   if (!mmf_gemm7_supports(problems, num_problems, layout, epilogue, out_f32, extra))
     MMF_FAIL(MMF_E_UNSUPPORTED, "mmf_gemm_grouped: the persistent kernel takes NT / NN launches with bf16 output, K %% 32 == 0, K >= %d, N and the "
-             "leading dimensions of C / aux multiples of 8, and the flag sets of the fusion step", (NS + 1) * BK);
+             "leading dimensions of C / aux multiples of 8, and the flag sets of the fusion step (alpha only with the NN ReLU mask)", (NS + 1) * BK);
   GemmArgs a;
   a.nprob = num_problems;
   a.epi = epilogue;
   a.xcd_granule = mmf_xcd_granule();
-  a.alpha = 1.f;
-  a.drop_thresh = 0u;
-  a.site = 0u;
-  a.rng_state = nullptr;
+  a.alpha = extra ? extra->alpha : 1.f;
+  a.drop_thresh = (extra && (epilogue & MMF_EPI_DROPOUT)) ? mmf_drop_thresh(extra->dropout_p) : 0u;
+  a.site = extra ? extra->site : 0u;
+  a.rng_state = extra ? reinterpret_cast<const unsigned long long*>(extra->rng_state) : nullptr;
   int total = 0;
   int order[MMF_GEMM_MAX_PROBLEMS];                            // longest reduction first (see the walk in gemm7_body)
   for (int i = 0; i < num_problems; ++i) order[i] = i;
@@ -534,6 +550,7 @@ int mmf_gemm7_launch(const mmf_gemm_problem* problems, int num_problems, int lay
     a.tile_start[i] = total;
     total += ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     a.p[i] = p;
+    a.orig[i] = (short)order[i];
   }
   a.tile_start[num_problems] = total;
   static const int cus = [] { int c = mmf_device_cu_count(); return c > 0 ? c : 256; }();

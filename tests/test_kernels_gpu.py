@@ -185,8 +185,9 @@ def test_gemm6_epilogues_and_edge_tiles():
         lib.check(L.mmf_gemm_select_impl(0))
 
 
-def _persistent_case(layout, shapes_k, epi, wgs, seed0=0):
-    """one grouped launch on generation 6 and on generation 7 (persistent, `wgs` workgroups): -> (outputs6, outputs7, refs)"""
+def _persistent_case(layout, shapes_k, epi, wgs, seed0=0, alpha=1.0, dropout=None):
+    """one grouped launch on generation 6 and on generation 7 (persistent, `wgs` workgroups): -> (outputs6, outputs7, refs);
+    refs are without dropout (the caller compares the kept elements)"""
     L = lib.load()
     probs6, probs7, refs = [], [], []
     for i, (M, N, K, pad) in enumerate(shapes_k):
@@ -207,7 +208,7 @@ def _persistent_case(layout, shapes_k, epi, wgs, seed0=0):
         if epi & EPI_RELU:
             ref = torch.relu(ref)
         if epi & EPI_MASK_AUX:
-            ref = ref * (aux16.float().cpu() > 0)
+            ref = ref * (aux16.float().cpu() > 0) * alpha
         if epi & EPI_ADD_AUX:
             ref = ref + aux16.float().cpu()
         refs.append(ref)
@@ -217,11 +218,11 @@ def _persistent_case(layout, shapes_k, epi, wgs, seed0=0):
         probs7.append((a16, b16, c7, bias, aux16))
     try:
         lib.check(L.mmf_gemm_select_impl(6))
-        ops.gemm_group(layout, probs6, epi)
+        ops.gemm_group(layout, probs6, epi, alpha=alpha, dropout=dropout)
         assert L.mmf_gemm_last_impl() == 6
         lib.check(L.mmf_gemm_select_impl(7))
         lib.check(L.mmf_gemm_set_persistent_workgroups(wgs))
-        ops.gemm_group(layout, probs7, epi)
+        ops.gemm_group(layout, probs7, epi, alpha=alpha, dropout=dropout)
         assert L.mmf_gemm_last_impl() == 7
         torch.cuda.synchronize()
     finally:
@@ -254,6 +255,32 @@ def test_gemm7_persistent_walks_tiles_bit_identical_to_gemm6(layout, wgs):
                 assert float((d > 0).float().mean()) < 0.02, f"epi {epi} problem {i}: {float((d > 0).float().mean()):.4f} of the elements differ"
             else:
                 assert torch.equal(a, b), f"epi {epi} problem {i}: generation 7 differs from generation 6"
+
+
+@pytest.mark.parametrize("wgs", [3, 0])
+def test_gemm7_training_epilogues_match_gemm6(wgs):
+    """The two epilogues a training step adds (round 4): dropout on the FFN hidden layer (NT, bias + ReLU + dropout: the mask is the
+    stateless hash of (state, site, caller's problem index, element) — the persistent kernel SORTS its problems by K, so the caller's
+    index must survive) and the dropout backward riding on the ReLU mask (NN, mask x alpha = 1 / (1 - p)).  Same masks and, without a
+    bias, the same bits as generation 6; kept elements equal the undropped reference x 1 / (1 - p)."""
+    shapes = [(520, 264, 160, 8), (300, 520, 768, 0), (1000, 392, 512, 8), (256, 256, 2048, 0)]
+    p = 0.25
+    ops.seed_dropout(1234)
+    c6, c7, refs = _persistent_case(GEMM_NT, shapes, EPI_BIAS | EPI_RELU, wgs, seed0=7, dropout=(p, 5))
+    for i, (a, b, r) in enumerate(zip(c6, c7, refs)):
+        assert not bool(torch.isnan(b.float()).any())
+        assert torch.equal(a == 0, b == 0), f"problem {i}: the two generations drew different masks"
+        kept = (b.float().cpu() != 0)
+        live = r > 0
+        frac = float(kept[live].float().mean())
+        assert abs(frac - (1 - p)) < 0.02, (i, frac)
+        assert rel(b.float().cpu()[kept], (r / (1 - p))[kept]) < 2 ** -7
+        d = (a.float() - b.float()).abs()                        # (bias: one bf16 ulp on a few elements, as in the test above)
+        assert float((d > 0).float().mean()) < 0.02
+    c6, c7, refs = _persistent_case(GEMM_NN, shapes, EPI_MASK_AUX, wgs, seed0=9, alpha=1.0 / (1 - p))
+    for i, (a, b, r) in enumerate(zip(c6, c7, refs)):
+        assert torch.equal(a, b), f"problem {i}: generation 7 differs from generation 6"
+        assert rel(b, r) < 2 ** -8
 
 
 def test_gemm7_is_the_automatic_choice_where_it_has_the_flag_set():
