@@ -34,6 +34,21 @@ _depth = 0          # >0 while inside an outer fusion forward: the arena was alr
 import os as _os
 _BRANCH_STREAM = _os.environ.get("MMF_HIER_STREAMS", "1") != "0"   # HierarchicalFusion: small branches beside MulT
 _MULT_NESTED = _os.environ.get("MMF_MULT_NESTED", "0") == "1"      # A/B: the two groups also when MulT runs inside HierarchicalFusion
+_INTERLEAVE = _os.environ.get("MMF_HIER_INTERLEAVE", "1") != "0"    # HierarchicalFusion: side branches issued BETWEEN MulT's stages
+# Side-branch thunks of an enclosing HierarchicalFusion, run one per stage of the MulT cross blocks (`_tick`).  A captured graph's nodes
+# are submitted in the order they were created: with the four (B, d)-row branches (~100 launches) created in front of MulT their forward
+# ran BEFORE MulT's first GEMM and — autograd executes in reverse creation order — their backward AFTER MulT's last, 250 + 300 us of
+# small kernels alone on the chip although they sit on their own stream (profiles/r04_step_timeline_hier.txt); created first-MulT-then-
+# branches the same serial section moves to the other end.  Created between MulT's stages they are submitted, forward and backward,
+# while MulT's chip-filling launches run.  None entries skip a stage.
+_between: list = []
+
+
+def _tick() -> None:
+    if _between:
+        fn = _between.pop(0)
+        if fn is not None:
+            fn()
 _RECAST = _os.environ.get("MMF_RECAST_EACH_STEP", "0") == "1"        # fp32 -> bf16 weight cast in every training forward
 _MULT_STREAMS = int(_os.environ.get("MMF_MULT_STREAMS", "2"))       # MulT's cross blocks as this many concurrent groups (1, 2, 3)
 # How the two groups are cut (round 3): "modality" = by QUERY modality — {t<-a, t<-v} + the text self-attention on one
@@ -168,7 +183,9 @@ def _cross_blocks(blocks: Sequence["CrossModalTransformer"], qs: Sequence[torch.
     qs[i]: bf16 (B*Tq_i, d); kvs[i]: bf16 (B*Tk_i, d); ress[i] (default qs[i]): the query rows as the residual of
     :205 — a separate handle when the caller fans its input out (ops.fanout) to sum the input gradients in one pass."""
     proj = _cross_in_proj(blocks, qs, kvs)                           # [Q0, KV0, Q1, KV1, ...]
+    _tick()
     att = _cross_attention(blocks, proj, B, Tqs, Tks, p)
+    _tick()
     return _cross_tail(blocks, att, qs if ress is None else ress, p)
 
 
@@ -190,9 +207,12 @@ def _cross_attention(blocks, proj, B, Tqs, Tks, p) -> List[torch.Tensor]:
 
 def _cross_tail(blocks, att, qs, p) -> List[torch.Tensor]:
     pre1 = ops.linear_group([(att[i], _lin(blk.attention.out_proj), qs[i]) for i, blk in enumerate(blocks)])
+    _tick()
     x = ops.layernorm_group([(pre1[i], blk.norm1.weight, blk.norm1.bias) for i, blk in enumerate(blocks)],
                             blocks[0].norm1.eps)
+    _tick()
     pre2 = ops.ffn_residual_group([(x[i], blk.ffn[0], blk.ffn[3]) for i, blk in enumerate(blocks)], dropout_p=p)
+    _tick()
     return ops.layernorm_group([(pre2[i], blk.norm2.weight, blk.norm2.bias) for i, blk in enumerate(blocks)],
                                blocks[0].norm2.eps)
 
@@ -592,12 +612,32 @@ class HierarchicalFusion(_FusionBase):
             main, side = torch.cuda.current_stream(), ops.branch_stream()
             _cat3(text_features, audio_features, video_features)        # shared cast issued before the fork
             side.wait_stream(main)
-            with torch.cuda.stream(side):
-                early = self.early_fusion(text_features, audio_features, video_features)
-                graph = self.graph_fusion(text_features, audio_features, video_features)
-                con = self.contrastive_fusion(text_features, audio_features, video_features, compute_contrastive_loss)
-                ada = self.adaptive_fusion(text_features, audio_features, video_features)
-            mult = self.mult_fusion(*seq)
+            res = {}
+
+            def on_side(name, fn):
+                def run():
+                    with torch.cuda.stream(side):
+                        res[name] = fn()
+                return run
+            tav = (text_features, audio_features, video_features)
+            thunks = [on_side("ada", lambda: self.adaptive_fusion(*tav)),                       # behind MulT's in-projections
+                      on_side("con", lambda: self.contrastive_fusion(*tav, compute_contrastive_loss)),      # ... attention cores
+                      on_side("early", lambda: self.early_fusion(*tav)),                        # ... out-projections
+                      None,                                                                      # (LayerNorm 1)
+                      on_side("graph", lambda: self.graph_fusion(*tav))]    # ... the FFN: the longest branch chain (3 GAT layers)
+            # backward runs beside the FFN's two dgrads, the first big launches of MulT's backward
+            if _INTERLEAVE:
+                _between[:] = thunks
+            else:
+                for fn in (thunks[2], thunks[4], thunks[1], thunks[0]):
+                    fn()
+            try:
+                mult = self.mult_fusion(*seq)
+                while _between:                                         # (a MulT path without those stages)
+                    _tick()
+            finally:
+                del _between[:]
+            early, graph, con, ada = res["early"], res["graph"], res["con"], res["ada"]
             main.wait_stream(side)
             for t in [early, graph] + [v for dct in (con, ada) for v in synth_flat(dct)]:
                 t.record_stream(main)                                   # produced on `side`, consumed on `main` from here on
