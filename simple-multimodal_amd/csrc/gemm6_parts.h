@@ -116,8 +116,15 @@ __device__ __forceinline__ unsigned piece_voff(int p, int ld, int lane) {
 
 // tile t of problem P -> (m0, n0): super-rows of 8 m-tiles, n fastest across a super-row (gemm4.hip)
 __device__ __forceinline__ void tile_origin(const mmf_gemm_problem& P, const int t, int& m0, int& n0) {
-  constexpr int GROUP_M = 8;
   const int tiles_m = (P.M + BM - 1) / BM, tiles_n = (P.N + BN - 1) / BN;
+  // super-rows of 8 m-tiles.  (Round 4 tried the height that makes an XCD's 32 concurrent tiles touch the fewest operand panels — 32 / tiles_n
+  // for narrow outputs, 11 x 3 instead of 8 x 3 + 8 x 1 at N = 768: the step got SLOWER, 2.027 -> 2.052 ms same box.)  MMF_GEMM_GROUPM
+  // (build-time) pins another height for A/Bs.
+#ifdef MMF_GEMM_GROUPM
+  constexpr int GROUP_M = MMF_GEMM_GROUPM;
+#else
+  constexpr int GROUP_M = 8;
+#endif
   const int grp = t / (GROUP_M * tiles_n), rem = t % (GROUP_M * tiles_n);
   const int gm = min(GROUP_M, tiles_m - grp * GROUP_M);
   m0 = (grp * GROUP_M + rem % gm) * BM;
