@@ -1,19 +1,23 @@
-// Grouped bf16 GEMM, PERSISTENT one-wave-per-SIMD form (round 4): the 256 x 256 tile / 128 x 128 wave-tile kernel of gemm6.hip with
-// one workgroup per CU walking a list of tiles, its LDS ring running on ACROSS tile boundaries.
+// Grouped bf16 GEMM, persistent one-wave-per-SIMD form on v_mfma_f32_16x16x32_bf16 (round 4, late): gemm7.hip's persistent workgroups, ring
+// and drain with the OTHER MFMA shape in the k-loop.
 //
-// Why.  A K = 768 tile of gemm6 is 2.7 us of prologue (the ring fill: 128 KiB per CU requested by all 256 CUs at once), 15.4 us of
-// k-loop and 4-5 us of epilogue, and in a launch of one to three rounds every CU is in the same phase at the same time: the
-// prologue is an HBM burst with the matrix pipe idle, the epilogue a store burst (rounds 2-3; ablation
-// -DMMF_G6_DBG=64).  Here
-//   * workgroup w (one per CU, grid = min(tiles, CUs)) takes the tiles w, w + grid, ... of the launch's XCD-aware tile order
-//     (mmf_xcd_tile: an XCD's 32 workgroups still share A / B panels in its L2);
-//   * the LDS-DMA stream never stops: while tile j's last NS stages are multiplied, the refills of the ring fetch the first NS
-//     stages of tile j + 1 (descriptors and per-lane source offsets switch at the hand-over of stage KT - NS), so tile j + 1's
-//     first fragments are read behind the last MFMAs of tile j — no ring fill except the workgroup's very first;
-//   * a tile's outputs are stored between its last stage and the next tile's first; the stores are not waited for (the stage
-//     hand-overs keep their piece-only vmcnt counts: with stores in flight they wait for MORE than they need, never for less —
-//     vmcnt counts loads and stores together) and drain under the next tile's k-loop.
-// NT and NN, bf16 output, every K a multiple of 32 and >= (NS + 1) * 32; everything else stays on gemm6 (gemm.hip).
+// Why.  Under matrix load the part runs at the socket power limit, not at its clock ceiling (profiles/r04_clock_under_load.txt: 1.62 GHz of
+// 2.4), and the clock it holds depends on the MFMA shape: bare register-operand loops deliver 2,047 TF with 16x16x32 against 1,790-1,823 with
+// 32x32x16 on the same box (tools/mfma_shape_bench.hip; MI355X_MICROARCH.md 'DVFS give-back' (7): 1.12-1.15x), at equal cycles per FLOP and
+// equal LDS bytes per FLOP (a 128 x 128 wave tile needs 16 one-KiB fragments per 32 k-columns either way).
+// What changes against gemm7.hip:
+//   * a wave's 128 x 128 quadrant is 8 x 8 accumulator tiles of 16 x 16 (four registers each, the same 256 AGPRs); a stage (32 k-columns)
+//     is ONE k-step of 64 MFMAs; D is n x m as before (a lane holds four consecutive n of one row m);
+//   * fragments are 16 rows x 32 k.  The k-contiguous image gets another swizzle — chunk ^ 2 ((row >> 3) & 1) instead of chunk ^ ((row >> 2) & 3):
+//     the 16-row read is serviced in the hardware's four 16-lane groups {0-3, 12-15, 20-27}, ... and the old image made it two-way
+//     (simulated with tools/lds_image_check.py's bank model: 8 cycles -> 4); the k-major image ([32][256], transposed reads) is unchanged;
+//   * all sixteen fragments of stage g + 1 are read during stage g into a second register set, so the stage hand-over stands at the TOP of a
+//     stage (after four MFMAs): behind it stage g + 1 is readable and stage g's own slot — read a stage ago — is refilled at once, NS stages
+//     ahead instead of NS - 1.  The two register sets alternate, so the k-loop is unrolled by two and K must be a multiple of 64;
+//   * flag sets without a bias start a tile's accumulators from a zero C operand in a peeled first stage; with a bias, from 64 MFMAs of the
+//     bias' three-way bf16 split against ones (gemm7: 16);
+//   * the drain writes each accumulator tile's four packed values as one 8-byte LDS store; whole-row reads and stores as in gemm7.
+// NT and NN, bf16 output, K % 64 == 0 and K >= 6 * 32; everything else stays on gemm7 / gemm6 (gemm.hip).
 #include <algorithm>
 #include "gemm6_parts.h"
 
@@ -23,6 +27,12 @@ constexpr int BK = 32, NS = 4;
 constexpr int TILE = 256 * BK * 2, STAGE = 2 * TILE, PPO = BK / 8, PPW = 2 * PPO;   // 16 KiB per operand tile, 8 pieces per wave and stage
 
 typedef int i32x4_t __attribute__((ext_vector_type(4)));
+
+// compile-time loop: f(integral_constant<int, 0>{}), ..., f(integral_constant<int, N - 1>{}) — immediates of the asm reads need constants
+template <int... I, class F>
+__device__ __forceinline__ void static_for_seq(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_seq(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f)); }
 
 // what the fetch side needs of the NEXT tile (wave-uniform): first element of each operand tile, bytes from there to the operand's
 // last valid element (< 2 GiB: host), bytes per stage of the n-operand, stages
@@ -47,6 +57,16 @@ __device__ __forceinline__ int to_sgpr(int x) {
   // read the scalar the vector ALU wrote
   asm volatile("s_nop 0\n\tv_readfirstlane_b32 %0, %1\n\ts_nop 4" : "=s"(r) : "v"(x));
   return r;
+}
+
+// per-lane source offset of 1-KiB piece p (the inverse of the image).  k-major operands: gemm6_parts.h's image.  k-contiguous operands
+// ([256 rows][32 k]): 8-row subtiles of 512 B, 16-byte chunk ch of row `row` in slot ch ^ 2 ((row >> 3) & 1) of its 64-byte row
+template <bool KR>
+__device__ __forceinline__ unsigned piece_voff16(int p, int ld, int lane) {
+  if constexpr (KR) return piece_voff<true, BK>(p, ld, lane);
+  const int st = 2 * p + (lane >> 5), w = lane & 31;
+  const int row = 8 * st + (w >> 2), ch = (w & 3) ^ (2 * (st & 1));
+  return (unsigned)(row * ld * 2 + ch * 16);
 }
 
 template <bool B_KR>
@@ -86,21 +106,23 @@ __device__ __forceinline__ void locate_tile(const GemmArgs& args, const int tota
 // START from (bias_init below).
 template <int CT>
 __device__ __forceinline__ void drain_tile(const GemmArgs& args, const int pi, const mmf_gemm_problem& P, const int mb, const int nb,
-                                           f32x16_t (&acc)[4][4], char* region, const int lane) {
+                                           f32x4_t (&acc)[8][8], char* region, const int lane) {
   constexpr bool AUX = (CT & (MMF_EPI_MASK_AUX | MMF_EPI_ADD_AUX)) != 0;
   constexpr bool DROP = (CT & MMF_EPI_DROPOUT) != 0;
-  // dropout on the (activated) outputs, the mask of gemm6's epilogue: element m * N + n of the caller's problem `orig[pi]`
   const unsigned drop_key = DROP ? mmf_rng_key(*args.rng_state, args.site, (unsigned)args.orig[pi]) : 0u;
   const float drop_scale = DROP ? 1.f / (1.f - (float)args.drop_thresh * (1.f / 4294967296.f)) : 1.f;
-  const float alpha = (CT & MMF_EPI_MASK_AUX) ? args.alpha : 1.f;            // 1 / (1 - p) of a dropout backward rides on the ReLU mask
-  const int r = lane & 31, h = lane >> 5, q = lane >> 4, cq = lane & 15;
-  // region offsets: accumulator layout (8 bytes at chunk c = 4 tn + g, half h, of row r), whole-row layout (16-byte chunk cq of row 4 it + q)
-  const unsigned wr_base = (unsigned)(r * 256 + 8 * h + 16 * (r & 15));
+  const float alpha = (CT & MMF_EPI_MASK_AUX) ? args.alpha : 1.f;
+  // accumulator tile [tn][tm]: lane (j = l & 15, g4 = l >> 4) holds C[m = 16 tm + j][n = 16 tn + 4 g4 + 0..3]: four consecutive n = 8 bytes of
+  // bf16 at row rr = 16 s + j of the 32-row block (s = tm & 1), 16-byte chunk c = 2 tn + (g4 >> 1), half g4 & 1.  Region layout as gemm7:
+  // chunk c of row r at r * 256 + ((c ^ (r & 15)) << 4) — a 16-lane group covers 16 rows = 16 different slots, the four groups two chunks
+  // x two halves: conflict-free.
+  const int j = lane & 15, g4 = lane >> 4, q = lane >> 4, cq = lane & 15;
+  auto acc_at = [&](int s, int tn) {
+    const unsigned rr = (unsigned)(16 * s + j), c = (unsigned)(2 * tn + (g4 >> 1));
+    return region + rr * 256 + ((c ^ (rr & 15)) << 4) + 8 * (g4 & 1);
+  };
   const unsigned rd_base = (unsigned)(q * 256 + ((cq ^ q) << 4));
-  auto acc_at = [&](int c) { return region + (wr_base ^ (unsigned)(c << 4)); };
   auto row_at = [&](int it) { return region + it * 1024 + (rd_base ^ (unsigned)((it & 3) << 6)); };
-  // global side: lane's column chunk is fixed (8 bf16 at nb + 8 cq), its row walks 32 tm + 4 it + q.  Range-checked buffer accesses
-  // against [base, last valid element]: rows past M fall outside; columns past N get an out-of-range offset.
   const bool col_ok = nb + 8 * cq < P.N;
   const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(P.C, 0, (int)((((long)P.M - 1) * P.ldc + P.N) * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(AUX ? P.aux : P.C), 0,
@@ -110,47 +132,44 @@ __device__ __forceinline__ void drain_tile(const GemmArgs& args, const int pi, c
   const unsigned c_row4 = (unsigned)(4 * P.ldc * 2), a_row4 = (unsigned)(4 * P.ldaux * 2);
 
   u32x4_t auxr[2][8];
-  auto load_aux = [&](int tm, int slot) {
+  auto load_aux = [&](int tb, int slot) {
 #pragma unroll
     for (int it = 0; it < 8; ++it)
-      auxr[slot][it] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(ars, a_off0 + (unsigned)(8 * tm + it) * a_row4, 0, 0));
+      auxr[slot][it] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(ars, a_off0 + (unsigned)(8 * tb + it) * a_row4, 0, 0));
   };
   if constexpr (AUX) { load_aux(0, 0); load_aux(1, 1); }
-  // (scheduling fences between the groups: without them the compiler hoists all 256 accumulator reads of the unrolled drain to its
-  // head and spills what it cannot hold — accumulators included)
 #pragma unroll
-  for (int tm = 0; tm < 4; ++tm) {
-    u32x2_t axv[4][4];
+  for (int tb = 0; tb < 4; ++tb) {                             // 32-row block of the quadrant
+    u32x2_t axv[2][8];
     if constexpr (AUX) {
 #pragma unroll
-      for (int it = 0; it < 8; ++it) *reinterpret_cast<u32x4_t*>(row_at(it)) = auxr[tm & 1][it];
+      for (int it = 0; it < 8; ++it) *reinterpret_cast<u32x4_t*>(row_at(it)) = auxr[tb & 1][it];
 #pragma unroll
-      for (int tn = 0; tn < 4; ++tn)
+      for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) axv[tn][g] = *reinterpret_cast<const u32x2_t*>(acc_at(4 * tn + g));
+        for (int tn = 0; tn < 8; ++tn) axv[s][tn] = *reinterpret_cast<const u32x2_t*>(acc_at(s, tn));
       __builtin_amdgcn_sched_barrier(0);
-      if (tm + 2 < 4) load_aux(tm + 2, tm & 1);
+      if (tb + 2 < 4) load_aux(tb + 2, tb & 1);
       __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
-    for (int tn = 0; tn < 4; ++tn) {
-      // (the tile passes through an opaque statement HERE: its sixteen accumulator reads cannot be hoisted to the head of the drain,
-      // where hipcc otherwise reads 160-250 accumulator registers into vector registers at once and spills the aux pieces in flight)
-      asm volatile("" : "+a"(acc[tn][tm]));
+    for (int s = 0; s < 2; ++s) {
+      const int tm = 2 * tb + s;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        f32x4_t v = {acc[tn][tm][4 * g], acc[tn][tm][4 * g + 1], acc[tn][tm][4 * g + 2], acc[tn][tm][4 * g + 3]};
+      for (int tn = 0; tn < 8; ++tn) {
+        asm volatile("" : "+a"(acc[tn][tm]));                  // (reads of the accumulators are not hoisted to the head of the drain)
+        f32x4_t v = acc[tn][tm];
         if constexpr (CT & MMF_EPI_RELU) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
         }
         if constexpr (DROP) {
-          const unsigned idx = (unsigned)(mb + 32 * tm + r) * (unsigned)P.N + (unsigned)(nb + 32 * tn + 8 * g + 4 * h);
+          const unsigned idx = (unsigned)(mb + 16 * tm + j) * (unsigned)P.N + (unsigned)(nb + 16 * tn + 4 * g4);
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = mmf_keep(drop_key, idx + e, args.drop_thresh) ? v[e] * drop_scale : 0.f;
         }
         if constexpr (AUX) {
-          const u32x2_t a = axv[tn][g];
+          const u32x2_t a = axv[s][tn];
           const float a0 = bf16lo(a[0]), a1 = bf16hi(a[0]), a2 = bf16lo(a[1]), a3 = bf16hi(a[1]);
           if constexpr (CT & MMF_EPI_MASK_AUX) {
             v[0] = a0 > 0.f ? v[0] * alpha : 0.f; v[1] = a1 > 0.f ? v[1] * alpha : 0.f;
@@ -159,7 +178,7 @@ __device__ __forceinline__ void drain_tile(const GemmArgs& args, const int pi, c
             v[0] += a0; v[1] += a1; v[2] += a2; v[3] += a3;
           }
         }
-        *reinterpret_cast<u32x2_t*>(acc_at(4 * tn + g)) = u32x2_t{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        *reinterpret_cast<u32x2_t*>(acc_at(s, tn)) = u32x2_t{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -167,7 +186,7 @@ __device__ __forceinline__ void drain_tile(const GemmArgs& args, const int pi, c
 #pragma unroll
     for (int it = 0; it < 8; ++it) w[it] = *reinterpret_cast<const u32x4_t*>(row_at(it));
 #pragma unroll
-    for (int it = 0; it < 8; ++it) __builtin_amdgcn_raw_buffer_store_b128(w[it], crs, c_off0 + (unsigned)(8 * tm + it) * c_row4, 0, 0);
+    for (int it = 0; it < 8; ++it) __builtin_amdgcn_raw_buffer_store_b128(w[it], crs, c_off0 + (unsigned)(8 * tb + it) * c_row4, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
   }
 }
@@ -185,9 +204,8 @@ __device__ __forceinline__ void drain_tile(const GemmArgs& args, const int pi, c
 //   * the ring fill fetches NS - 1 stages and the late half of the NS-th, so the very first stage already finds its early pieces
 //     to issue.
 template <bool B_KR, int CT>
-__device__ __forceinline__ void gemm7_body(const GemmArgs& args, const int total_tiles, char* smem) {
+__device__ __forceinline__ void gemm8_body(const GemmArgs& args, const int total_tiles, char* smem) {
   constexpr bool A_KR = false;
-  constexpr int WA = BK, WB = B_KR ? 256 : BK;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -213,8 +231,8 @@ __device__ __forceinline__ void gemm7_body(const GemmArgs& args, const int total
   auto set_voff = [&](unsigned (&v)[PPW], int la, int lb) {
 #pragma unroll
     for (int i = 0; i < PPO; ++i) {
-      v[i] = piece_voff<A_KR, BK>(wave + 4 * i, la, lane);
-      v[PPO + i] = piece_voff<B_KR, BK>(wave + 4 * i, lb, lane);
+      v[i] = piece_voff16<A_KR>(wave + 4 * i, la, lane);
+      v[PPO + i] = piece_voff16<B_KR>(wave + 4 * i, lb, lane);
     }
   };
   set_voff(voff, lda, ldb);
@@ -250,18 +268,16 @@ __device__ __forceinline__ void gemm7_body(const GemmArgs& args, const int total
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  // ---- the workgroup's one ring fill: NS - 1 stages and the late half of the NS-th (the same two-instruction pieces: no LDS-DMA the
-  // compiler knows of, so the LDS accesses of drain_tile are never preceded by a compiler-placed vmcnt(0)) ---------------------------
+  // ---- the workgroup's one ring fill: NS whole stages (the same two-instruction pieces: no LDS-DMA the compiler knows of, so the LDS
+  // accesses of drain_tile are never preceded by a compiler-placed vmcnt(0)) -------------------------------------------------------
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
     const unsigned rb = lds_pieces + (unsigned)(s * STAGE);
     hot_piece(std::integral_constant<int, 0>{}, rb); hot_piece(std::integral_constant<int, 1>{}, rb);
     hot_piece(std::integral_constant<int, 2>{}, rb); hot_piece(std::integral_constant<int, 3>{}, rb);
-    if (s + 1 < NS) {
-      hot_piece(std::integral_constant<int, 4>{}, rb); hot_piece(std::integral_constant<int, 5>{}, rb);
-      hot_piece(std::integral_constant<int, 6>{}, rb); hot_piece(std::integral_constant<int, 7>{}, rb);
-      advance(dA, stepA); advance(dB, stepB);                // afterwards: stage NS - 1, the one being fetched
-    }
+    hot_piece(std::integral_constant<int, 4>{}, rb); hot_piece(std::integral_constant<int, 5>{}, rb);
+    hot_piece(std::integral_constant<int, 6>{}, rb); hot_piece(std::integral_constant<int, 7>{}, rb);
+    advance(dA, stepA); advance(dB, stepB);                  // afterwards: stage NS, the next one to fetch
   }
 
   bool has_next = walk(1) < total_tiles;
@@ -277,140 +293,141 @@ __device__ __forceinline__ void gemm7_body(const GemmArgs& args, const int total
   }
 
   // ---- fragment addressing (tile-independent) ----------------------------------------------------------------------------------------
-  unsigned la0, la1, lb0, lb1;
-  Frag4<A_KR>::lane_parts(WA, lane, la0, la1);
-  Frag4<B_KR>::lane_parts(WB, lane, lb0, lb1);
+  // k-contiguous operand: lane (i = l & 15, g = l >> 4) reads chunk g of row 16 blk + i: one lane part + 1024 blk.
+  // k-major operand: group g = l >> 4 takes k rows 8 g .. 8 g + 7 of columns 16 jj .. 16 jj + 15 by two transposed reads
+  // (lane 4 q + p: row 8 g [+ 4] + q, columns 4 p .. 4 p + 3): lane parts (by the parity of jj) + 512 (jj >> 1).
   const unsigned smem_base = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)smem;
-  const unsigned qa = (unsigned)((WA / 32) * 2048 * 4 * wm);
-  const unsigned qb = (unsigned)(B_KR ? 512 * 4 * wn : (WB / 32) * 2048 * 4 * wn);
-  la0 += smem_base + qa; la1 += smem_base + qa;
-  lb0 += smem_base + TILE + qb; lb1 += smem_base + TILE + qb;
+  const unsigned lrow = (unsigned)(512 * ((lane >> 3) & 1) + 64 * (lane & 7) + 16 * ((lane >> 4) ^ (2 * ((lane >> 3) & 1))));
+  const unsigned tq = (unsigned)((lane >> 2) & 3), tp = (unsigned)(lane & 3), tg = (unsigned)(lane >> 4);
+  // (the image's swizzle is chunk ^ ((k >> 2) & 3) = chunk ^ (2 (g & 1) + [second read]): its bit 1 meets the column block's parity, so the
+  // lane parts come in an even-jj and an odd-jj form)
+  auto ltr = [&](unsigned par, unsigned hi) {
+    return 4096 * tg + 64 * (tq + 4 * hi) + 32 * (par ^ (tg & 1)) + 16 * ((tp >> 1) ^ hi) + 8 * (tp & 1);
+  };
+  const unsigned ltlo0 = ltr(0, 0), ltlo1 = ltr(1, 0), lthi0 = ltr(0, 1), lthi1 = ltr(1, 1);
+  const unsigned a_base = smem_base + (unsigned)(1024 * 8 * wm) + lrow;
+  const unsigned b_base = smem_base + TILE + (B_KR ? (unsigned)(2048 * wn) : (unsigned)(1024 * 8 * wn) + lrow);
+  (void)ltlo0; (void)ltlo1; (void)lthi0; (void)lthi1;
 
-  f32x16_t acc[4][4];                 // [tn][tm]; set to the bias (or to zero) by bias_init in front of every tile
+  f32x4_t acc[8][8];                  // [tn][tm]: C[m = 16 tm + (l & 15)][n = 16 tn + 4 (l >> 4) + 0..3] of the wave's quadrant
 
-  // Bias.  In the accumulator layout a lane would hold 64 bias values per tile (columns nb + 32 tn + 8 g + 4 h + e) through the
-  // drain, on top of the aux pieces in flight: with them the drain spills.  Instead the tile's accumulators START from the bias: lane
-  // r keeps ONE value per 32-column block tn (bias[nb + 32 tn + r], loaded a tile ahead: at the head of the previous tile's drain) and
-  // sixteen MFMAs spread them as outer products with a ones fragment,
-  //     D[n][m] = sum_k A[n][k] B[k][m],  A[n][0..2] = the exact three-way bf16 split of bias[n],  B[0..2][m] = 1
-  // (exact in f32: 8 + 8 + 8 mantissa bits; attention2.hip does the same with its row statistics).  16 of a K = 768 tile's 784 MFMAs.
+  // Two sets of the sixteen fragments of a stage: while the MFMAs run on one, the next stage's are read into the other.
+  struct Frags {
+    u32x4_t a[8];
+    u32x4_t b[8];                     // k-major B: {lo.x, lo.y, hi.x, hi.y} of the two transposed reads
+  };
+  Frags F[2];
+  auto geta = [&](const Frags& f, int i) { return __builtin_bit_cast(bf16x8_t, f.a[i]); };
+  auto getb = [&](const Frags& f, int i) { return __builtin_bit_cast(bf16x8_t, f.b[i]); };
+  // read #u of the stage at ring offset `so` into f: u < 8: A fragment u; u >= 8: B fragment u - 8 (k-major: both halves)
+  auto rd = [&](Frags& f, auto uc, const unsigned so) {
+    constexpr int U = decltype(uc)::value, J = U & 7;
+    if constexpr (U < 8) f.a[J] = lds_read_b128<1024 * J>(a_base + so);
+    else if constexpr (!B_KR) f.b[J] = lds_read_b128<1024 * J>(b_base + so);
+    else {
+      const u32x2_t lo_ = lds_read_tr<512 * (J >> 1)>(b_base + ((J & 1) ? ltlo1 : ltlo0) + so);
+      const u32x2_t hi_ = lds_read_tr<512 * (J >> 1)>(b_base + ((J & 1) ? lthi1 : lthi0) + so);
+      f.b[J] = u32x4_t{lo_[0], lo_[1], hi_[0], hi_[1]};
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto frag_tie = [](Frags& f) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.a[2]), "+v"(f.a[3]), "+v"(f.a[4]), "+v"(f.a[5]), "+v"(f.a[6]), "+v"(f.a[7]),
+                 "+v"(f.b[0]), "+v"(f.b[1]), "+v"(f.b[2]), "+v"(f.b[3]), "+v"(f.b[4]), "+v"(f.b[5]), "+v"(f.b[6]), "+v"(f.b[7]));
+  };
+
+  // Bias: with a bias the tile's accumulators START from it — 64 MFMAs of the bias' exact three-way bf16 split (8 + 8 + 8 mantissa bits)
+  // against a ones fragment, D[n][m] = sum_k A[n][k] B[k][m] with A[n][0..2] = split, B[0..2][m] = 1 (lanes 0-15 carry k = 0 .. 7).
+  // Lane i keeps ONE value per 16-column block tn (bias[nb + 16 tn + (l & 15)], loaded a tile ahead).  Without a bias the tile's
+  // first stage takes a zero C operand.
   constexpr bool use_bias = (CT & MMF_EPI_BIAS) != 0;
-  float bcur[4] = {0.f, 0.f, 0.f, 0.f};
-  auto load_bias = [&](float (&b)[4], const TileDst& d) {
+  float bcur[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  auto load_bias = [&](float (&b)[8], const TileDst& d) {
     const mmf_gemm_problem& P = args.p[d.pi];
     const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.bias), 0, P.N * 4, 0x00020000);
-    const unsigned off = (unsigned)((d.n0 + 128 * wn + (lane & 31)) * 4);
+    const unsigned off = (unsigned)((d.n0 + 128 * wn + (lane & 15)) * 4);
 #pragma unroll
-    for (int tn = 0; tn < 4; ++tn)                              // (the builtin returns the 32 bits as an integer)   past N: 0
-      b[tn] = __uint_as_float((unsigned)__builtin_amdgcn_raw_buffer_load_b32(brs, off + (unsigned)(32 * tn * 4), 0, 0));
+    for (int tn = 0; tn < 8; ++tn)                              // (the builtin returns the 32 bits as an integer)   past N: 0
+      b[tn] = __uint_as_float((unsigned)__builtin_amdgcn_raw_buffer_load_b32(brs, off + (unsigned)(16 * tn * 4), 0, 0));
   };
   auto split3 = [&](float x) {
-    const bool lo = lane < 32;
+    const bool lo = lane < 16;
     const unsigned hh = __float_as_uint(x) & 0xffff0000u;
     const float r1 = x - __uint_as_float(hh);
     const unsigned mm = __float_as_uint(r1) & 0xffff0000u;
     const float r2 = r1 - __uint_as_float(mm);
     const unsigned ll = __float_as_uint(r2) & 0xffff0000u;
-    const u32x4_t w = {lo ? ((hh >> 16) | mm) : 0u, lo ? (ll >> 16) : 0u, 0u, 0u};
-    return __builtin_bit_cast(bf16x8_t, w);
+    return u32x4_t{lo ? ((hh >> 16) | mm) : 0u, lo ? (ll >> 16) : 0u, 0u, 0u};
   };
-  auto bias_init = [&](const float (&b)[4]) {
-    const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const u32x4_t ow = {lane < 32 ? 0x3f803f80u : 0u, lane < 32 ? 0x00003f80u : 0u, 0u, 0u};
-    // one opaque copy of the ones fragment per row block: sixteen MFMAs with the same operands would be merged into four (or, without
-    // a bias, into ONE) and their results copied into the other accumulator tiles register by register
-    u32x4_t ones[4] = {ow, ow, ow, ow};
+  auto bias_init = [&](const float (&b)[8]) {
+    const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
+    const u32x4_t ow = {lane < 16 ? 0x3f803f80u : 0u, lane < 16 ? 0x00003f80u : 0u, 0u, 0u};
+    u32x4_t ones[8] = {ow, ow, ow, ow, ow, ow, ow, ow};       // opaque copies: identical MFMAs would be merged and their results copied
 #pragma unroll
-    for (int tm = 0; tm < 4; ++tm) asm volatile("" : "+v"(ones[tm]));
+    for (int tm = 0; tm < 8; ++tm) asm volatile("" : "+v"(ones[tm]));
 #pragma unroll
-    for (int tn = 0; tn < 4; ++tn) {
-      u32x4_t bw = __builtin_bit_cast(u32x4_t, use_bias ? split3(b[tn]) : __builtin_bit_cast(bf16x8_t, u32x4_t{0u, 0u, 0u, 0u}));
+    for (int tn = 0; tn < 8; ++tn) {
+      u32x4_t bw = split3(b[tn]);
       asm volatile("" : "+v"(bw));
 #pragma unroll
-      for (int tm = 0; tm < 4; ++tm) {
-        acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, bw), __builtin_bit_cast(bf16x8_t, ones[tm]), zero, 0, 0, 0);
+      for (int tm = 0; tm < 8; ++tm) {
+        acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, bw), __builtin_bit_cast(bf16x8_t, ones[tm]), zero, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
   };
   if constexpr (use_bias) load_bias(bcur, cd);
 
-  vm_wait<PPW * (NS - 2) + 4>();      // stage 0 landed (with the bias loads behind the pieces this waits for more: once per workgroup)
+  vm_wait<PPW * (NS - 1)>();          // stage 0 landed (with the bias loads behind the pieces this waits for more: once per workgroup)
   __builtin_amdgcn_s_barrier();
-  Frag4<A_KR> fa[2];
-  Frag4<B_KR> fb[2];
-  fa[0].template issue<WA, 0, 0>(la0, la1);
-  fb[0].template issue<WB, 0, 0>(lb0, lb1);
-  frag_wait(fa[0], fb[0]);
+  static_for<16>([&](auto uc) { rd(F[0], uc, 0u); });
+  frag_tie(F[0]);
 
-  auto mf = [&](const Frag4<A_KR>& a, const Frag4<B_KR>& b, int i) {
-    const int tm = i >> 2, tn = i & 3;
-    acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b.get(tn), a.get(tm), acc[tn][tm], 0, 0, 0);
-    // an empty statement that "uses" the tile: the MFMA builtin has no side effect, and in this kernel instruction selection sank the
-    // sixteen MFMAs of a substep below the reads and pieces that are written between them (each down to its next use, the same
-    // tile's MFMA of the following substep); the volatile statement chains it into the order of the other asm statements
-    asm volatile("" ::"a"(acc[tn][tm]));
-    __builtin_amdgcn_sched_barrier(0);
-  };
-#define MMF_G7_READ(dstA, dstB, G, u, so)                                                              \
-  do {                                                                                                 \
-    if ((u) == 0) dstA.template issue1<WA, G, 0, 0>(la0 + (so), la1 + (so));                            \
-    if ((u) == 1) dstA.template issue1<WA, G, 0, 1>(la0 + (so), la1 + (so));                            \
-    if ((u) == 2) dstA.template issue1<WA, G, 0, 2>(la0 + (so), la1 + (so));                            \
-    if ((u) == 3) dstA.template issue1<WA, G, 0, 3>(la0 + (so), la1 + (so));                            \
-    if ((u) == 4) dstB.template issue1<WB, G, 0, 0>(lb0 + (so), lb1 + (so));                            \
-    if ((u) == 5) dstB.template issue1<WB, G, 0, 1>(lb0 + (so), lb1 + (so));                            \
-    if ((u) == 6) dstB.template issue1<WB, G, 0, 2>(lb0 + (so), lb1 + (so));                            \
-    if ((u) == 7) dstB.template issue1<WB, G, 0, 3>(lb0 + (so), lb1 + (so));                            \
-    __builtin_amdgcn_sched_barrier(0);                                                                 \
-  } while (0)
-
-  // One stage (gemm6.hip's schedule, BK = 32: two k-substeps of sixteen MFMAs).  g: the workgroup's running stage count (ring slot
-  // g % NS).  kt == ksw: this is stage KT - NS of its tile — from its hand-over on the refills fetch the NEXT tile (or nothing).
-  // The hand-over counts PIECES only.  Stores, aux and bias loads of a drain may be younger than the pieces waited for: the wait
-  // then covers more than it needs (safe whether or not the hardware retires loads and stores in one order), never less.
-  auto stage = [&](const unsigned g, const int kt, const int ksw) {
+  // One stage = 64 MFMAs on fragment set CUR while the next stage's sixteen fragments are read into the other set.
+  // g: the workgroup's running stage count (ring slot g % NS); kt: the stage's index in its tile.
+  //   MFMAs 0..3, then the hand-over: stage g + 1 has landed for everyone, and — its fragments having been read during stage g - 1 —
+  //   nobody reads slot g % NS any more: it is refilled with stage g + NS behind MFMAs 28..43; the reads of stage g + 1 follow MFMAs
+  //   4..19 (k-major B: two transposed reads per fragment);
+  //   behind MFMAs 44 / 45: both descriptors one stage on, or — after the tile's stage KT - NS - 1, whose refill was the tile's last —
+  //   switched (with the per-lane offsets) to the next tile's first stage: scalar / vector SELECTS, no branch (gemm7.hip).
+  // FIRST: a tile's first stage without a bias (C operand zero).
+  auto stage = [&](auto curc, auto firstc, const unsigned g, const int kt, const int ksw) {
+    constexpr int CUR = decltype(curc)::value;
+    constexpr bool FIRST = decltype(firstc)::value;
+    Frags& fc = F[CUR];
+    Frags& fn = F[CUR ^ 1];
     unsigned long long swmask;
     const Desc nA = mkdesc(ns.Ab, ns.recA), nB = mkdesc(ns.Bb, ns.recB);
-    const unsigned so = (g % NS) * STAGE;
-    const unsigned ring_cur = lds_pieces + so, ring_prev = lds_pieces + ((g + NS - 1) % NS) * STAGE;
-    // substep 0: MFMA i (i < 8) is followed by one read of substep 1's fragments; the early pieces (second half of the stage whose
-    // late half went out at the end of the previous stage) ride behind MFMAs 8, 10, 12, 14
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      mf(fa[0], fb[0], i);
-      if (i < 8) MMF_G7_READ(fa[1], fb[1], 1, i, so);
-      if (i == 8)  hot_piece(std::integral_constant<int, 4>{}, ring_prev);
-      if (i == 10) hot_piece(std::integral_constant<int, 5>{}, ring_prev);
-      if (i == 12) hot_piece(std::integral_constant<int, 6>{}, ring_prev);
-      if (i == 14) hot_piece(std::integral_constant<int, 7>{}, ring_prev);
-    }
-    frag_wait(fa[1], fb[1]);
-    // substep 1: four MFMAs, the stage hand-over, then MFMAs 4..11 each followed by one read of the next stage's first fragments and
-    // MFMAs 12..15 by the late pieces
+    const unsigned ring_cur = lds_pieces + (g % NS) * STAGE;
     const unsigned sn = ((g + 1) % NS) * STAGE;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) mf(fa[1], fb[1], i);
-    vm_wait<PPW * (NS - 2)>();
-    __builtin_amdgcn_s_barrier();                              // the next stage landed for everyone; nobody reads this one any more
-    __builtin_amdgcn_sched_barrier(0);
-    // Behind the hand-over: advance the descriptors, or switch them (and the per-lane offsets) to the next tile's first stage — as
-    // SELECTS, not as a branch (with a branch here hipcc duplicated the rest of the stage into both arms and joined the two copies'
-    // 256 accumulator registers with v_accvgpr_mov chains behind the k-loop), in four portions of at most nine instructions behind
-    // MFMAs 4..7 (a wave issues eight instructions per 32-cycle MFMA).  The selects are inline asm: ONE compare feeds all of them
-    // (hipcc re-derived the condition per portion: 45 instructions), and left to itself it computes all of it between the vmcnt
-    // wait and the barrier, in front of an idle matrix pipe.
-#pragma unroll
-    for (int i = 4; i < 16; ++i) {
-      mf(fa[1], fb[1], i);
-      if (i < 12) MMF_G7_READ(fa[0], fb[0], 0, i - 4, sn);
-      if (i == 4) {                                            // both descriptors one stage on (eight scalar instructions)
+    const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
+    static_for<64>([&](auto ic) {
+      constexpr int i = decltype(ic)::value, tn = i >> 3, tm = i & 7;
+      if constexpr (FIRST) acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(getb(fc, tn), geta(fc, tm), zero, 0, 0, 0);
+      else                 acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(getb(fc, tn), geta(fc, tm), acc[tn][tm], 0, 0, 0);
+      asm volatile("" ::"a"(acc[tn][tm]));                    // (chains the MFMA into the order of the asm statements: gemm7.hip)
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (i == 3) {
+        vm_wait<PPW * (NS - 2)>();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (i >= 4 && i < 20) rd(fn, std::integral_constant<int, (i >= 4 && i < 20) ? i - 4 : 0>{}, sn);
+      if constexpr (i == 28) hot_piece(std::integral_constant<int, 0>{}, ring_cur);
+      if constexpr (i == 30) hot_piece(std::integral_constant<int, 1>{}, ring_cur);
+      if constexpr (i == 32) hot_piece(std::integral_constant<int, 2>{}, ring_cur);
+      if constexpr (i == 34) hot_piece(std::integral_constant<int, 3>{}, ring_cur);
+      if constexpr (i == 36) hot_piece(std::integral_constant<int, 4>{}, ring_cur);
+      if constexpr (i == 38) hot_piece(std::integral_constant<int, 5>{}, ring_cur);
+      if constexpr (i == 40) hot_piece(std::integral_constant<int, 6>{}, ring_cur);
+      if constexpr (i == 42) hot_piece(std::integral_constant<int, 7>{}, ring_cur);
+      if constexpr (i == 44) {                                           // both descriptors one stage on (eight scalar instructions)
         advance(dA, stepA);
         advance(dB, stepB);
         asm volatile("" ::"s"(dA.lo), "s"(dA.hi), "s"(dA.rec), "s"(dB.lo), "s"(dB.hi), "s"(dB.rec));
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (i == 5) {                                            // one compare, seven scalar selects, the lane mask for the vector selects
+      if constexpr (i == 46) {                                           // one compare, seven scalar selects, the lane mask for the vector selects
         asm volatile("s_cmp_eq_u32 %8, %16\n\t"
                      "s_cselect_b32 %0, %9, %0\n\ts_cselect_b32 %1, %10, %1\n\ts_cselect_b32 %2, %11, %2\n\t"
                      "s_cselect_b32 %3, %12, %3\n\ts_cselect_b32 %4, %13, %4\n\ts_cselect_b32 %5, %14, %5\n\t"
@@ -420,34 +437,42 @@ __device__ __forceinline__ void gemm7_body(const GemmArgs& args, const int total
                      : "scc");
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (i == 6) {
+      if constexpr (i == 48) {
         asm volatile("v_cndmask_b32_e64 %0, %0, %4, %8\n\tv_cndmask_b32_e64 %1, %1, %5, %8\n\t"
                      "v_cndmask_b32_e64 %2, %2, %6, %8\n\tv_cndmask_b32_e64 %3, %3, %7, %8"
                      : "+v"(voff[0]), "+v"(voff[1]), "+v"(voff[2]), "+v"(voff[3])
                      : "v"(voffn[0]), "v"(voffn[1]), "v"(voffn[2]), "v"(voffn[3]), "s"(swmask));
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (i == 7) {
+      if constexpr (i == 50) {
         asm volatile("v_cndmask_b32_e64 %0, %0, %4, %8\n\tv_cndmask_b32_e64 %1, %1, %5, %8\n\t"
                      "v_cndmask_b32_e64 %2, %2, %6, %8\n\tv_cndmask_b32_e64 %3, %3, %7, %8"
                      : "+v"(voff[4]), "+v"(voff[5]), "+v"(voff[6]), "+v"(voff[7])
                      : "v"(voffn[4]), "v"(voffn[5]), "v"(voffn[6]), "v"(voffn[7]), "s"(swmask));
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (i == 12) hot_piece(std::integral_constant<int, 0>{}, ring_cur);
-      if (i == 13) hot_piece(std::integral_constant<int, 1>{}, ring_cur);
-      if (i == 14) hot_piece(std::integral_constant<int, 2>{}, ring_cur);
-      if (i == 15) hot_piece(std::integral_constant<int, 3>{}, ring_cur);
-    }
-    frag_wait(fa[0], fb[0]);
+    });
+    frag_tie(fn);
   };
+  using C0 = std::integral_constant<int, 0>; using C1 = std::integral_constant<int, 1>;
+  using Yes = std::integral_constant<bool, true>; using No = std::integral_constant<bool, false>;
 
   char* const region = smem + NS * STAGE + wave * 8192;
   unsigned g = 0;
   for (;;) {
-    bias_init(bcur);
-    const int ksw = KT - NS;                                   // >= 1 (host)
-    for (int kt = 0; kt < KT; ++kt, ++g) stage(g, kt, ksw);
+    const int ksw = KT - NS - 1;                               // >= 1 (host: KT even, >= NS + 2)
+    if constexpr (use_bias) {
+      bias_init(bcur);
+      stage(C0{}, No{}, g, 0, ksw);
+    } else {
+      stage(C0{}, Yes{}, g, 0, ksw);
+    }
+    stage(C1{}, No{}, g + 1, 1, ksw);
+    g += 2;
+    for (int kt = 2; kt < KT; kt += 2, g += 2) {
+      stage(C0{}, No{}, g, kt, ksw);
+      stage(C1{}, No{}, g + 1, kt + 1, ksw);
+    }
     // ---- the tile's outputs ----------------------------------------------------------------------------------------------------------
     const mmf_gemm_problem& P = args.p[cd.pi];
     const int mb = cd.m0 + 128 * wm, nb = cd.n0 + 128 * wn;
@@ -468,65 +493,58 @@ __device__ __forceinline__ void gemm7_body(const GemmArgs& args, const int total
     }
   }
   vm_wait<0>();                       // the zero-range refills behind the last tile
-#undef MMF_G7_READ
 }
 
 template <bool B_KR, int CT>
 __global__ __launch_bounds__(NTHREADS, 1)
-void gemm7_persistent_kernel(const GemmArgs args, const int total_tiles) {
+void gemm8_persistent_kernel(const GemmArgs args, const int total_tiles) {
   // the ring and, behind it, one 8-KiB output staging region per wave: all 160 KiB of the CU
   __shared__ __attribute__((aligned(1024))) char smem[NS * STAGE + 4 * 8192];
-  gemm7_body<B_KR, CT>(args, total_tiles, smem);
+  gemm8_body<B_KR, CT>(args, total_tiles, smem);
 }
 
 // the (layout, flag set) pairs of the fusion step's NT / NN launches: in-projections (NT, bias), FFN1 (NT, bias + ReLU), out-projection
 // and FFN2 (NT, bias + residual), plain NT, dgrads (NN, none), dH (NN, ReLU mask), dX (NN, residual gradient)
 template <bool B_KR, int CT>
-void launch7(const GemmArgs& a, int total, int grid, hipStream_t s) {
-  hipLaunchKernelGGL((gemm7_persistent_kernel<B_KR, CT>), dim3(grid), dim3(NTHREADS), 0, s, a, total);
+void launch8(const GemmArgs& a, int total, int grid, hipStream_t s) {
+  hipLaunchKernelGGL((gemm8_persistent_kernel<B_KR, CT>), dim3(grid), dim3(NTHREADS), 0, s, a, total);
 }
-bool launch7_select(int layout, int eflags, const GemmArgs* a, int total, int grid, hipStream_t s) {   // a == nullptr: only ask
+bool launch8_select(int layout, int eflags, const GemmArgs* a, int total, int grid, hipStream_t s) {   // a == nullptr: only ask
   if (layout == MMF_GEMM_NT) {
-    if (eflags == 0)                                      { if (a) launch7<false, 0>(*a, total, grid, s); return true; }
-    if (eflags == MMF_EPI_BIAS)                           { if (a) launch7<false, MMF_EPI_BIAS>(*a, total, grid, s); return true; }
-    if (eflags == (MMF_EPI_BIAS | MMF_EPI_RELU))          { if (a) launch7<false, MMF_EPI_BIAS | MMF_EPI_RELU>(*a, total, grid, s); return true; }
-    if (eflags == (MMF_EPI_BIAS | MMF_EPI_ADD_AUX))       { if (a) launch7<false, MMF_EPI_BIAS | MMF_EPI_ADD_AUX>(*a, total, grid, s); return true; }
+    if (eflags == 0)                                      { if (a) launch8<false, 0>(*a, total, grid, s); return true; }
+    if (eflags == MMF_EPI_BIAS)                           { if (a) launch8<false, MMF_EPI_BIAS>(*a, total, grid, s); return true; }
+    if (eflags == (MMF_EPI_BIAS | MMF_EPI_RELU))          { if (a) launch8<false, MMF_EPI_BIAS | MMF_EPI_RELU>(*a, total, grid, s); return true; }
+    if (eflags == (MMF_EPI_BIAS | MMF_EPI_ADD_AUX))       { if (a) launch8<false, MMF_EPI_BIAS | MMF_EPI_ADD_AUX>(*a, total, grid, s); return true; }
     if (eflags == (MMF_EPI_BIAS | MMF_EPI_RELU | MMF_EPI_DROPOUT)) {       // FFN hidden layer in training mode
-      if (a) launch7<false, MMF_EPI_BIAS | MMF_EPI_RELU | MMF_EPI_DROPOUT>(*a, total, grid, s);
+      if (a) launch8<false, MMF_EPI_BIAS | MMF_EPI_RELU | MMF_EPI_DROPOUT>(*a, total, grid, s);
       return true;
     }
   } else if (layout == MMF_GEMM_NN) {
-    if (eflags == 0)                                      { if (a) launch7<true, 0>(*a, total, grid, s); return true; }
-    if (eflags == MMF_EPI_MASK_AUX)                       { if (a) launch7<true, MMF_EPI_MASK_AUX>(*a, total, grid, s); return true; }
-    if (eflags == MMF_EPI_ADD_AUX)                        { if (a) launch7<true, MMF_EPI_ADD_AUX>(*a, total, grid, s); return true; }
+    if (eflags == 0)                                      { if (a) launch8<true, 0>(*a, total, grid, s); return true; }
+    if (eflags == MMF_EPI_MASK_AUX)                       { if (a) launch8<true, MMF_EPI_MASK_AUX>(*a, total, grid, s); return true; }
+    if (eflags == MMF_EPI_ADD_AUX)                        { if (a) launch8<true, MMF_EPI_ADD_AUX>(*a, total, grid, s); return true; }
   }
   return false;
 }
 }  // namespace
 
-static int g_persistent_wgs = [] { const char* e = getenv("MMF_GEMM7_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();
-int mmf_gemm7_persistent_wgs() { return g_persistent_wgs; }   // (gemm8.hip shares the setting)
-extern "C" int mmf_gemm_set_persistent_workgroups(int n) {
-  if (n < 0 || n > 65536) MMF_FAIL(MMF_E_SHAPE, "mmf_gemm_set_persistent_workgroups: %d not in 0..65536", n);
-  g_persistent_wgs = n;
-  return MMF_OK;
-}
+int mmf_gemm7_persistent_wgs();        // gemm7.hip: MMF_GEMM7_WGS / mmf_gemm_set_persistent_workgroups
 
 // whether the persistent kernel can take this launch (gemm.hip asks before selecting it)
-bool mmf_gemm7_supports(const mmf_gemm_problem* problems, int num_problems, int layout, int epilogue, int out_f32, const mmf_gemm_extra* extra) {
-  if (out_f32 || !launch7_select(layout, epilogue, nullptr, 0, 0, nullptr)) return false;
+bool mmf_gemm8_supports(const mmf_gemm_problem* problems, int num_problems, int layout, int epilogue, int out_f32, const mmf_gemm_extra* extra) {
+  if (out_f32 || !launch8_select(layout, epilogue, nullptr, 0, 0, nullptr)) return false;
   if (extra && extra->alpha != 1.f && !(layout == MMF_GEMM_NN && epilogue == MMF_EPI_MASK_AUX)) return false;   // alpha rides on the mask only
   if ((epilogue & MMF_EPI_DROPOUT) && !(extra && extra->rng_state)) return false;
   for (int i = 0; i < num_problems; ++i) {
     const mmf_gemm_problem& p = problems[i];
-    if (p.K % BK || p.K < (NS + 1) * BK || (p.N & 7) || (p.ldc & 7) || (p.aux && (p.ldaux & 7))) return false;
+    if (p.K % (2 * BK) || p.K < (NS + 2) * BK || (p.N & 7) || (p.ldc & 7) || (p.aux && (p.ldaux & 7))) return false;
   }
   return true;
 }
 
-int mmf_gemm7_launch(const mmf_gemm_problem* problems, int num_problems, int layout, int epilogue,
+int mmf_gemm8_launch(const mmf_gemm_problem* problems, int num_problems, int layout, int epilogue,
                      int out_f32, const mmf_gemm_extra* extra, hipStream_t s) {
-  if (!mmf_gemm7_supports(problems, num_problems, layout, epilogue, out_f32, extra))
+  if (!mmf_gemm8_supports(problems, num_problems, layout, epilogue, out_f32, extra))
     MMF_FAIL(MMF_E_UNSUPPORTED, "mmf_gemm_grouped: the persistent kernel takes NT / NN launches with bf16 output, K %% 32 == 0, K >= %d, N and the "
              "leading dimensions of C / aux multiples of 8, and the flag sets of the fusion step (alpha only with the NN ReLU mask)", (NS + 1) * BK);
   GemmArgs a;
@@ -538,7 +556,7 @@ int mmf_gemm7_launch(const mmf_gemm_problem* problems, int num_problems, int lay
   a.site = extra ? extra->site : 0u;
   a.rng_state = extra ? reinterpret_cast<const unsigned long long*>(extra->rng_state) : nullptr;
   int total = 0;
-  int order[MMF_GEMM_MAX_PROBLEMS];                            // longest reduction first (see the walk in gemm7_body)
+  int order[MMF_GEMM_MAX_PROBLEMS];                            // longest reduction first (see the walk in gemm8_body)
   for (int i = 0; i < num_problems; ++i) order[i] = i;
   std::stable_sort(order, order + num_problems, [&](int x, int y) { return problems[x].K > problems[y].K; });
   for (int i = 0; i < num_problems; ++i) {
@@ -555,9 +573,9 @@ int mmf_gemm7_launch(const mmf_gemm_problem* problems, int num_problems, int lay
   }
   a.tile_start[num_problems] = total;
   static const int cus = [] { int c = mmf_device_cu_count(); return c > 0 ? c : 256; }();
-  const int want = g_persistent_wgs > 0 ? g_persistent_wgs : cus;
+  const int want = mmf_gemm7_persistent_wgs() > 0 ? mmf_gemm7_persistent_wgs() : cus;
   const int grid = total < want ? total : want;
-  launch7_select(layout, epilogue, &a, total, grid, s);
+  launch8_select(layout, epilogue, &a, total, grid, s);
   MMF_CHECK_LAUNCH("mmf_gemm_grouped(v7)");
   return MMF_OK;
 }
