@@ -25,13 +25,10 @@ bool mmf_gemm6_supports_epi(int epilogue, int out_f32);
 int mmf_gemm7_launch(const mmf_gemm_problem* problems, int num_problems, int layout, int epilogue,
                      int out_f32, const mmf_gemm_extra* extra, hipStream_t s);   // gemm7.hip: gemm6's tile, persistent workgroups
 bool mmf_gemm7_supports(const mmf_gemm_problem* problems, int num_problems, int layout, int epilogue, int out_f32, const mmf_gemm_extra* extra);
-int mmf_gemm8_launch(const mmf_gemm_problem* problems, int num_problems, int layout, int epilogue,
-                     int out_f32, const mmf_gemm_extra* extra, hipStream_t s);   // gemm8.hip: gemm7 on v_mfma_f32_16x16x32_bf16
-bool mmf_gemm8_supports(const mmf_gemm_problem* problems, int num_problems, int layout, int epilogue, int out_f32, const mmf_gemm_extra* extra);
 
 // Implementation switch (A/B runs in one process: tools/gemm7_bench.py): 0 = automatic (default), 2 / 6 / 7 = that kernel for every
 // launch it supports.  Default from MMF_GEMM_IMPL, else automatic.
-static bool impl_built(int v) { return v == 0 || v == 2 || v == 6 || v == 7 || v == 8; }
+static bool impl_built(int v) { return v == 0 || v == 2 || v == 6 || v == 7; }
 static int g_gemm_impl = [] {
   const char* e = getenv("MMF_GEMM_IMPL");
   const int v = (e && e[0] >= '0' && e[0] <= '9') ? e[0] - '0' : 0;
@@ -39,8 +36,6 @@ static int g_gemm_impl = [] {
 }();
 // MMF_GEMM_PERSIST=0: NT / NN launches stay on gemm6 (one tile per workgroup) instead of its persistent form
 static const int g_persist = [] { const char* e = getenv("MMF_GEMM_PERSIST"); return e ? atoi(e) : 1; }();
-// MMF_GEMM_SHAPE16=1: persistent launches whose K is a multiple of 64 run on the 16x16x32 form (gemm8.hip)
-static const int g_shape16 = [] { const char* e = getenv("MMF_GEMM_SHAPE16"); return e ? atoi(e) : 0; }();
 
 // The automatic choice: the 256 x 256 one-wave-per-SIMD tile for every launch it supports that gives at least a quarter of the CUs a
 // tile (wgrad: half — a single layer's weight gradient keeps the 256 x 128 ring and its twice as many tiles), gemm2 for the rest.
@@ -56,7 +51,7 @@ static thread_local int t_last_impl = 0;
 extern "C" int mmf_gemm_last_impl(void) { return t_last_impl; }
 extern "C" int mmf_gemm_select_impl(int impl) {
   if (!impl_built(impl))
-    MMF_FAIL(MMF_E_UNSUPPORTED, "mmf_gemm_select_impl: generation %d is not built (0 = automatic, 2, 6, 7, 8; 1 / 3 left in round 3, 4 / 5 in round 4)", impl);
+    MMF_FAIL(MMF_E_UNSUPPORTED, "mmf_gemm_select_impl: generation %d is not built (0 = automatic, 2, 6, 7; 1 / 3 left in round 3, 4 / 5 in round 4)", impl);
   g_gemm_impl = impl;
   return MMF_OK;
 }
@@ -88,8 +83,6 @@ extern "C" int mmf_gemm_grouped_ex(const mmf_gemm_problem* problems, int num_pro
   if (impl == 0) impl = auto_impl(problems, num_problems, layout);
   const bool ok6 = mmf_gemm6_supports(problems, num_problems, layout) && mmf_gemm6_supports_epi(epilogue, out_f32);
   if (impl == 6 && !pinned && g_persist && mmf_gemm7_supports(problems, num_problems, layout, epilogue, out_f32, extra)) impl = 7;
-  if (impl == 7 && !pinned && g_shape16 && mmf_gemm8_supports(problems, num_problems, layout, epilogue, out_f32, extra)) impl = 8;
-  if (impl == 8 && !mmf_gemm8_supports(problems, num_problems, layout, epilogue, out_f32, extra)) impl = 7;
   if (impl == 7 && !mmf_gemm7_supports(problems, num_problems, layout, epilogue, out_f32, extra)) impl = 6;
   if (impl == 6 && !ok6) impl = 2;
   t_last_impl = impl;
@@ -119,6 +112,5 @@ extern "C" int mmf_gemm_grouped_ex(const mmf_gemm_problem* problems, int num_pro
   if (impl == 2) return mmf_gemm2_launch(problems, num_problems, layout, epilogue, out_f32, extra, s);
   if (impl == 6) return mmf_gemm6_launch(problems, num_problems, layout, epilogue, out_f32, extra, s);
   if (impl == 7) return mmf_gemm7_launch(problems, num_problems, layout, epilogue, out_f32, extra, s);
-  if (impl == 8) return mmf_gemm8_launch(problems, num_problems, layout, epilogue, out_f32, extra, s);
-  MMF_FAIL(MMF_E_UNSUPPORTED, "mmf_gemm_grouped: kernel generation %d is not built (2, 6, 7, 8)", impl);
+  MMF_FAIL(MMF_E_UNSUPPORTED, "mmf_gemm_grouped: kernel generation %d is not built (2, 6, 7)", impl);
 }

@@ -505,7 +505,6 @@ bool launch7_select(int layout, int eflags, const GemmArgs* a, int total, int gr
 }  // namespace
 
 static int g_persistent_wgs = [] { const char* e = getenv("MMF_GEMM7_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();
-int mmf_gemm7_persistent_wgs() { return g_persistent_wgs; }   // (gemm8.hip shares the setting)
 extern "C" int mmf_gemm_set_persistent_workgroups(int n) {
   if (n < 0 || n > 65536) MMF_FAIL(MMF_E_SHAPE, "mmf_gemm_set_persistent_workgroups: %d not in 0..65536", n);
   g_persistent_wgs = n;
