@@ -167,9 +167,12 @@ __global__ void adamw_advance_kernel(long long* __restrict__ step, float* __rest
   hp[6] = (float)(1.0 - pow(b2, (double)t));
 }
 
+#ifndef MMF_OPT_GRID
+#define MMF_OPT_GRID 2048         // workgroups of the streaming kernels (8 per CU)
+#endif
 inline int opt_grid(int64_t n) {
   int64_t g = ((n >> 2) + OPT_THREADS - 1) / OPT_THREADS;
-  if (g > 2048) g = 2048;
+  if (g > MMF_OPT_GRID) g = MMF_OPT_GRID;
   return g < 1 ? 1 : (int)g;
 }
 
