@@ -228,12 +228,24 @@ def make_step(workload, model, xs, arena):
         if workload == "mult":
             out = model(*xs)
             fused = out["fused_features"]
-            loss = fused.sum()
+            # the loss VALUE feeds nothing on the device: it is reduced on the branch stream, beside the backward's first launches, and
+            # joined at the end of the step (one graph node less on the single-stream middle of the step)
+            if fused.is_cuda:
+                from mmfusion import ops
+                main, side = torch.cuda.current_stream(), ops.branch_stream()
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    loss = fused.sum()
+            else:
+                loss = fused.sum()
             # d(sum)/d(fused) is a tensor of ones: hand autograd a resident one instead of letting loss.backward() build it
             # with a fill and an expand kernel per step (two graph nodes on the step's single-stream critical path)
             if "g" not in ones:
                 ones["g"] = torch.ones_like(fused)
             torch.autograd.backward([fused], [ones["g"]])
+            if fused.is_cuda:
+                main.wait_stream(side)
+                loss.record_stream(main)
         else:
             out = model(*xs, compute_contrastive_loss=True)
             fused, aux = out["fused_features"], list(out["contrastive_losses"].values())
