@@ -122,6 +122,29 @@ def test_meld_shaped_model_matches_oracle(fusion_type):
         assert want is not None, n
         got = params[n].grad.detach().float().cpu()
         assert l2_rel(got, want) <= 0.2, f"{fusion_type}: grad {n} rel L2 {l2_rel(got, want):.3e}"
+    # ... and EVERY other parameter the oracle differentiates ("a handful of parameters"): the fusion module's, the heads'
+    # and the encoder tails', with the module-level tolerances of tests/test_parity_gpu.py (ReLU-fed tensors looser: a unit on the other
+    # side of zero moves its whole row); tensors whose oracle gradient is zero up to cancellation noise must be (near-)zero here too
+    from test_parity_gpu import GP_L2, GP_L2_RELU, RELU_FED
+    relu_fed = RELU_FED + ("classifier.classifier.0.", "projection.")
+    scale = max(float(v.grad.norm()) for v in P.values() if v.grad is not None)
+    worst, checked = (0.0, ""), 0
+    for n, prm in params.items():
+        want = P[n].grad if n in P else None
+        if want is None or prm.grad is None or "temporal_lstm" in n:
+            continue
+        got = prm.grad.detach().float().cpu()
+        if float(want.norm()) <= 1e-6 * scale:
+            assert float(got.norm()) <= 1e-3 * scale, f"{fusion_type}: {n} should have a (near-)zero gradient"
+            continue
+        e = l2_rel(got, want)
+        checked += 1
+        if e > worst[0]:
+            worst = (e, n)
+        tol = GP_L2_RELU if any(s in n for s in relu_fed) else GP_L2
+        assert e <= tol, f"{fusion_type}: grad {n} rel L2 {e:.3e} > {tol}"
+    print(f"model level ({fusion_type}): {checked} parameter gradients checked, worst rel L2 {worst[0]:.3e} ({worst[1]})")
+    assert checked >= (60 if fusion_type == "hierarchical" else 10)
 
 
 @pytest.mark.parametrize("T,use_adapter", [(499, False), (499, True), (1, False)])
