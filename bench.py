@@ -356,7 +356,7 @@ _SYMBOL = {"gemm2_grouped_kernel<NT,bf16>": ["gemm2_grouped_kernel<false, false,
            "gemm6_grouped_kernel<NT,bf16>": ["gemm6_grouped_kernel<false, false, 32, 4, false>"],
            "gemm6_grouped_kernel<NN,bf16>": ["gemm6_grouped_kernel<false, true, 32, 4, false>"],
            "gemm7_grouped_kernel<NT,bf16>": ["gemm7_persistent_kernel<false, 0>", "gemm7_persistent_kernel<false, 1>",
-                                             "gemm7_persistent_kernel<false, 3>", "gemm7_persistent_kernel<false, 9>"],
+                                             "gemm7_persistent_kernel<false, 3>", "gemm7_persistent_kernel<false, 9>", "gemm7_persistent_kernel<false, 67>"],
            "gemm7_grouped_kernel<NN,bf16>": ["gemm7_persistent_kernel<true, 0>", "gemm7_persistent_kernel<true, 4>",
                                              "gemm7_persistent_kernel<true, 8>"],
            "attn_fwd_kernel<96>": ["attn_fwd2n_kernel<96, false>", "attn_fwd2_kernel<96, false, 2>", "attn_fwd2_kernel<96, false>"],
